@@ -1,0 +1,242 @@
+/*
+ * spice_amd.h — C ABI of the MI355X (gfx950) pruning hot path.
+ *
+ * One shared library (libspice_amd.so) exports every entry point below with C
+ * linkage.  Conventions, identical for all of them:
+ *   - every pointer named *_base / student / teacher / labels / preds / target /
+ *     conf / out3 / grad / workspace / d_items is a DEVICE pointer owned by the
+ *     caller; the library never allocates, frees or retains device memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     every call only enqueues work on it and returns without synchronising;
+ *   - the return value is 0 on success, SPICE_ERR_* for an argument problem
+ *     detected on the host before anything is enqueued, or a hipError_t value
+ *     when a launch fails; no C++ exception crosses the boundary;
+ *   - "plan" functions are pure host code: they turn a list of tensor shapes into
+ *     a table of fixed-size work items which the caller uploads once and re-uses
+ *     for every call on tensors of that structure.
+ *
+ * The reference toolkit (EPIC 2.0, Python) has no FFI of its own; each entry
+ * point names the Python call site whose arithmetic it replaces.
+ */
+#ifndef SPICE_AMD_H
+#define SPICE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPICE_ABI_VERSION 1
+
+#define SPICE_OK 0
+#define SPICE_ERR_ARG 10001         /* null pointer, negative size, misaligned base */
+#define SPICE_ERR_UNSUPPORTED 10002 /* shape outside what the kernels implement */
+#define SPICE_ERR_WORKSPACE 10003   /* workspace smaller than *_workspace_bytes() */
+
+/* ABI version the library was built with (compare with SPICE_ABI_VERSION). */
+int spice_abi_version(void);
+/* Static, human-readable text for a return code of this library. */
+const char *spice_error_string(int code);
+
+/* ------------------------------------------------------------------------- *
+ * (1) Per-output-channel importance reduction over many weight tensors.
+ *
+ * Replaces, per Conv2d and per calibration batch,
+ *   grad.abs() * weight.abs() -> .sum(dim=(1,2,3)) -> scores[module] += ...
+ *     (pruning/sensitivity_utils.py:61-66)
+ * and torch-pruning 1.6.0 MagnitudeImportance(p)'s per-layer term
+ *   weight.flatten(1).abs().pow(p).sum(1)
+ *     (constructed at pruning/pruner.py:268-270, pruning/pruning_core.py:143-145,
+ *      pruning/strategies.py:53; evaluated inside pruner.step(), pruning/pruner.py:495).
+ * All tensors of a model are addressed as element offsets from three base
+ * pointers so that one launch covers every layer.
+ * ------------------------------------------------------------------------- */
+typedef struct spice_rows_desc {
+    int64_t w_off;   /* first element of the [rows,row_len] row-major weight, from w_base */
+    int64_t g_off;   /* same tensor's gradient, from g_base (ignored unless mode TAYLOR)   */
+    int64_t out_off; /* first element of its [rows] score vector, from score_base          */
+    int64_t rows;    /* out_channels                                                       */
+    int64_t row_len; /* in_channels/groups * kh * kw                                       */
+} spice_rows_desc;
+
+typedef struct spice_rows_item {
+    int64_t w_off;
+    int64_t g_off;
+    int64_t out_off;
+    int32_t row_len;
+    int32_t n_rows;
+    int32_t lanes; /* lanes cooperating on one row: power of two, 1..64 */
+    int32_t flags; /* bit0: rows are 16-byte aligned and row_len % 4 == 0 */
+} spice_rows_item;
+
+#define SPICE_IMP_L1 0     /* sum |w|          */
+#define SPICE_IMP_L2 1     /* sum w*w          */
+#define SPICE_IMP_TAYLOR 2 /* sum |g| * |w|    */
+
+/* Host only.  Writes at most `capacity` items to `items` (may be NULL to count)
+ * and returns the number of items the layers need, or a negative SPICE_ERR_*. */
+int64_t spice_importance_plan(const spice_rows_desc *layers, int32_t n_layers,
+                              spice_rows_item *items, int64_t capacity);
+
+/* score[row] = (accumulate ? score[row] : 0) + reduction(row) for every row of
+ * every planned layer.  Deterministic: a fixed reduction tree per row. */
+int spice_importance_run(const float *w_base, const float *g_base, float *score_base,
+                         const spice_rows_item *d_items, int64_t n_items, int32_t mode,
+                         int32_t accumulate, void *stream);
+
+/* Per-INPUT-channel magnitude term of torch-pruning's MagnitudeImportance for a
+ * consumer layer: weight.transpose(0,1).flatten(1).abs().pow(p).sum(1).
+ * `inner` = kh*kw; the weight is [rows, cols*inner] row-major. */
+typedef struct spice_cols_desc {
+    int64_t w_off;
+    int64_t out_off; /* [cols] result vector, from score_base */
+    int64_t rows;    /* out_channels */
+    int64_t cols;    /* in_channels / groups */
+    int64_t inner;   /* kh*kw */
+} spice_cols_desc;
+
+typedef struct spice_cols_item {
+    int64_t w_off;   /* first element of the slab's first row, at the chunk's first column */
+    int64_t out_off; /* where this item's flat-column partial sums go, from partial_base    */
+    int32_t row_stride;
+    int32_t n_rows;  /* rows in this slab */
+    int32_t n_flat;  /* flat columns (cols*inner granularity) in this chunk, <= 1024 */
+    int32_t flags;   /* bit0: 16-byte aligned float4 path */
+} spice_cols_item;
+
+typedef struct spice_cols_fold {
+    int64_t part_off; /* first partial row of this layer, from partial_base */
+    int64_t out_off;  /* [cols] result, from score_base */
+    int32_t n_slabs;
+    int32_t n_flat;   /* cols*inner */
+    int32_t inner;
+    int32_t cols;
+} spice_cols_fold;
+
+/* Host only.  Returns the item count (stage 1); *n_folds receives the stage-2 record
+ * count (= n_layers) and *partial_elems the float elements of scratch stage 1 writes. */
+int64_t spice_importance_cols_plan(const spice_cols_desc *layers, int32_t n_layers,
+                                   spice_cols_item *items, int64_t capacity,
+                                   spice_cols_fold *folds, int64_t *partial_elems);
+
+int spice_importance_cols_run(const float *w_base, float *score_base, float *partial_base,
+                              const spice_cols_item *d_items, int64_t n_items,
+                              const spice_cols_fold *d_folds, int64_t n_folds, int32_t mode,
+                              void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * (2) Fused KD-Lite loss: temperature-softmax KL + cross-entropy in one pass.
+ *
+ * Replaces KDLiteLoss.forward (pruning/losses.py:127-162) = SegmentationLoss
+ * (:58-84) + PixelKDLoss (:22-55) + optional boundary mask (:109-119) and
+ * teacher-confidence weights (:121-125); called from the fine-tune loop at
+ * pruning/trainer.py:179.  Logits are fp32 NCHW contiguous, labels int64 NHW.
+ * ------------------------------------------------------------------------- */
+typedef struct spice_kdlite_params {
+    float temperature;
+    float alpha;
+    float boundary_weight;     /* > 1 enables the 3x3 label-boundary term          */
+    int32_t confidence_weight; /* non-zero enables the teacher max-prob weighting  */
+    int64_t ignore_index;      /* 255 in the reference                             */
+    const float *class_weight; /* device [C] or NULL (reference: 5 weights iff C==5) */
+} spice_kdlite_params;
+
+size_t spice_kdlite_workspace_bytes(int64_t n, int64_t c, int64_t h, int64_t w);
+
+/* out3 (device, 3 floats) = {total, ce, kd}.  If `grad` is non-NULL it receives
+ * coef_ce * d(ce)/d(student) + coef_kd * d(kd)/d(student), shape [N,C,H,W]; with
+ * coef_ce = alpha and coef_kd = 1 - alpha that is d(total)/d(student).
+ * If `upstream` (device, 3 floats = incoming gradients of total, ce, kd) is
+ * non-NULL the coefficients become upstream[0]*alpha + upstream[1] and
+ * upstream[0]*(1-alpha) + upstream[2] and coef_ce/coef_kd are ignored.
+ * The workspace's first int64 is incremented by the number of labels that are neither
+ * ignore_index nor in [0,C) (the reference raises for them); such pixels contribute
+ * nothing to ce.  The caller zeroes that word once after allocating the workspace.
+ * Bytes [16,80) of the workspace receive the eight fp64 pixel sums of the call:
+ * {sum valid*KL, n_valid, sum w*nll, sum w, sum boundary*KL, n_boundary,
+ *  sum conf*KL, sum conf}. */
+int spice_kdlite_forward(const float *student, const float *teacher, const int64_t *labels,
+                         int64_t n, int64_t c, int64_t h, int64_t w,
+                         const spice_kdlite_params *params, float *out3, float *grad,
+                         float coef_ce, float coef_kd, const float *upstream,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* x[i] *= *scale for i < n, skipped entirely on the device when *scale == 1. */
+int spice_scale_inplace(float *x, int64_t n, const float *scale, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * (3) mIoU confusion-matrix histogram.
+ *
+ * Replaces update_confusion_matrix (baseline/eval/metrics.py:8-19, duplicated at
+ * baseline/train_test_quant.py:14-24) and the confusion part of
+ * SegmentationMetrics.update (pruning/eval/metrics.py:47-70):
+ *   conf[t, p] += 1 for every pixel with 0 <= t < C   (rows = target, cols = pred).
+ * ------------------------------------------------------------------------- */
+size_t spice_confusion_workspace_bytes(int64_t n_pixels, int32_t num_classes);
+
+/* conf: device [C,C] int64, updated in place.  The workspace's first int64 is
+ * incremented by the number of pixels with a valid target but a prediction
+ * outside [0,C) (the reference fails on those); they are not counted in conf.
+ * The caller zeroes that word once after allocating the workspace. */
+int spice_confusion_update(const int64_t *preds, const int64_t *target, int64_t n_pixels,
+                           int32_t num_classes, int64_t *conf, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
+/* Same update with the arg-max fused in: preds = argmax over C of logits
+ * [N,C,HW] (first maximum wins, as torch.argmax), never materialised.
+ * Replaces baseline/eval/inference.py:47-48 and
+ * pruning/eval/components/core_evaluator.py:141-143.
+ * logits_dtype: 0 = fp32, 1 = fp16, 2 = bf16. */
+int spice_argmax_confusion_update(const void *logits, int32_t logits_dtype,
+                                  const int64_t *target, int64_t n, int64_t hw,
+                                  int32_t num_classes, int64_t *conf, void *workspace,
+                                  size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * (4) Channel gather: physically slice pruned tensors.
+ *
+ * Replaces torch-pruning 1.6.0's prune_conv_out_channels / prune_conv_in_channels /
+ * prune_batchnorm_out_channels (index_select + contiguous per tensor), executed
+ * inside pruner.step() (pruning/pruner.py:495).  One launch covers every tensor:
+ *   dst[o, i, k] = src[keep_out[o], keep_in[i], k]
+ * with 1-D tensors (bias, BN weight/bias/mean/var) as the cols = inner = 1 case.
+ * Elements are moved as 32-bit words, so the copy is bit-exact.
+ * ------------------------------------------------------------------------- */
+typedef struct spice_gather_desc {
+    int64_t src_off;     /* from src_base, elements */
+    int64_t dst_off;     /* from dst_base, elements */
+    int64_t idx_out_off; /* offset into idx_base of the dst_rows kept row ids, or -1 = identity */
+    int64_t idx_in_off;  /* offset into idx_base of the dst_cols kept col ids, or -1 = identity */
+    int64_t dst_rows;
+    int64_t dst_cols;
+    int64_t src_cols;
+    int64_t inner;
+} spice_gather_desc;
+
+typedef struct spice_gather_item {
+    int64_t src_off;     /* tensor origin (row 0) */
+    int64_t dst_off;     /* first destination row of this item */
+    int64_t idx_out_off; /* already advanced to this item's first row, or -1 */
+    int64_t idx_in_off;
+    int32_t row0;        /* first destination row of this item */
+    int32_t n_rows;
+    int32_t dst_cols;
+    int32_t src_cols;
+    int32_t inner;
+    int32_t lanes;
+    int32_t flags;       /* bit0: float4 row copy is legal */
+    int32_t pad_;
+} spice_gather_item;
+
+int64_t spice_gather_plan(const spice_gather_desc *tensors, int32_t n_tensors,
+                          spice_gather_item *items, int64_t capacity);
+
+int spice_gather_run(const float *src_base, float *dst_base, const int64_t *idx_base,
+                     const spice_gather_item *d_items, int64_t n_items, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPICE_AMD_H */

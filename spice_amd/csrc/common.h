@@ -1,0 +1,48 @@
+// Shared helpers for the gfx950 kernels of libspice_amd.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/spice_amd.h"
+
+#define SPICE_HIP_TRY(expr)                      \
+    do {                                         \
+        hipError_t spice_e_ = (expr);            \
+        if (spice_e_ != hipSuccess) {            \
+            (void)hipGetLastError();             \
+            return (int)spice_e_;                \
+        }                                        \
+    } while (0)
+
+#define SPICE_LAUNCH_CHECK() SPICE_HIP_TRY(hipGetLastError())
+
+namespace spice {
+
+constexpr int kWave = 64;
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Butterfly sum over the `width` lanes (power of two, <= 64) that share the
+// caller's aligned lane group; every lane of the group ends with the total.
+__device__ __forceinline__ float group_sum(float v, int width) {
+    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+}  // namespace spice

@@ -1,0 +1,127 @@
+// Kernel (4): channel gather.  dst[o, i, k] = src[keep_out[o], keep_in[i], k] for every tensor
+// of a model in one launch.  Pure HBM-bound copy of 32-bit words (bit-exact); kept rows are
+// copied with 16-byte accesses when no input-channel list breaks their contiguity.
+#include "common.h"
+
+namespace spice {
+
+constexpr int kGatherThreads = 256;
+constexpr int64_t kGatherTargetElems = 16384;
+
+__global__ __launch_bounds__(kGatherThreads) void gather_kernel(
+    const unsigned *__restrict__ src_base, unsigned *__restrict__ dst_base,
+    const long long *__restrict__ idx_base, const spice_gather_item *__restrict__ items,
+    int bases_vec_ok) {
+    const spice_gather_item it = items[blockIdx.x];
+    const int L = it.lanes;
+    const int tid = threadIdx.x;
+    const int sub = tid / L;
+    const int lane = tid & (L - 1);
+    const int groups = kGatherThreads / L;
+    const int row_len = it.dst_cols * it.inner;
+    const int64_t src_row_stride = (int64_t)it.src_cols * it.inner;
+    const unsigned *src = src_base + it.src_off;
+    unsigned *dst = dst_base + it.dst_off;
+    const long long *idx_out = it.idx_out_off >= 0 ? idx_base + it.idx_out_off : nullptr;
+    const long long *idx_in = it.idx_in_off >= 0 ? idx_base + it.idx_in_off : nullptr;
+    const bool vec = bases_vec_ok && (it.flags & 1);
+
+    for (int r = sub; r < it.n_rows; r += groups) {
+        const int64_t so = idx_out ? (int64_t)idx_out[r] : (int64_t)(it.row0 + r);
+        const unsigned *srow = src + so * src_row_stride;
+        unsigned *drow = dst + (int64_t)r * row_len;
+        if (idx_in == nullptr) {
+            if (vec) {
+                const uint4 *s4 = reinterpret_cast<const uint4 *>(srow);
+                uint4 *d4 = reinterpret_cast<uint4 *>(drow);
+                const int n4 = row_len >> 2;
+                int j = lane;
+                for (; j + 3 * L < n4; j += 4 * L) {
+                    const uint4 a = s4[j], b = s4[j + L], c = s4[j + 2 * L], d = s4[j + 3 * L];
+                    d4[j] = a;
+                    d4[j + L] = b;
+                    d4[j + 2 * L] = c;
+                    d4[j + 3 * L] = d;
+                }
+                for (; j < n4; j += L) d4[j] = s4[j];
+            } else {
+                for (int j = lane; j < row_len; j += L) drow[j] = srow[j];
+            }
+        } else if (it.inner == 1) {
+            for (int j = lane; j < row_len; j += L) drow[j] = srow[idx_in[j]];
+        } else {
+            const int inner = it.inner;
+            for (int j = lane; j < row_len; j += L) {
+                const int i = j / inner;
+                const int k = j - i * inner;
+                drow[j] = srow[idx_in[i] * (int64_t)inner + k];
+            }
+        }
+    }
+}
+
+}  // namespace spice
+
+using namespace spice;
+
+extern "C" int64_t spice_gather_plan(const spice_gather_desc *tensors, int32_t n_tensors,
+                                     spice_gather_item *items, int64_t capacity) {
+    if (n_tensors < 0 || (n_tensors > 0 && tensors == nullptr)) return -SPICE_ERR_ARG;
+    int64_t n = 0;
+    for (int32_t t = 0; t < n_tensors; ++t) {
+        const spice_gather_desc &d = tensors[t];
+        if (d.dst_rows < 0 || d.dst_cols < 0 || d.src_cols < 0 || d.inner < 1 || d.src_off < 0 ||
+            d.dst_off < 0 || d.idx_out_off < -1 || d.idx_in_off < -1)
+            return -SPICE_ERR_ARG;
+        if (d.idx_in_off < 0 && d.dst_cols != d.src_cols) return -SPICE_ERR_ARG;
+        if (d.dst_cols > d.src_cols) return -SPICE_ERR_ARG;
+        const int64_t row_len = d.dst_cols * d.inner;
+        const int64_t src_stride = d.src_cols * d.inner;
+        if (src_stride > INT32_MAX || d.dst_rows > INT32_MAX) return -SPICE_ERR_UNSUPPORTED;
+        if (d.dst_rows == 0 || row_len == 0) continue;
+        const bool vec = d.idx_in_off < 0 && (row_len % 4 == 0) && (d.src_off % 4 == 0) &&
+                         (d.dst_off % 4 == 0);
+        const int64_t units = vec ? row_len / 4 : row_len;
+        int L = kWave;
+        while (L > 1 && L > units) L >>= 1;
+        const int64_t groups = kGatherThreads / L;
+        int64_t rpi = kGatherTargetElems / row_len;
+        if (rpi < 1) rpi = 1;
+        rpi = ceil_div(rpi, groups) * groups;
+        const int64_t n_it = ceil_div(d.dst_rows, rpi);
+        rpi = ceil_div(ceil_div(d.dst_rows, n_it), groups) * groups;
+        for (int64_t r0 = 0; r0 < d.dst_rows; r0 += rpi, ++n) {
+            if (items == nullptr || n >= capacity) continue;
+            spice_gather_item &it = items[n];
+            it.src_off = d.src_off;
+            it.dst_off = d.dst_off + r0 * row_len;
+            it.idx_out_off = d.idx_out_off >= 0 ? d.idx_out_off + r0 : -1;
+            it.idx_in_off = d.idx_in_off;
+            it.row0 = (int32_t)r0;
+            it.n_rows = (int32_t)((d.dst_rows - r0 < rpi) ? d.dst_rows - r0 : rpi);
+            it.dst_cols = (int32_t)d.dst_cols;
+            it.src_cols = (int32_t)d.src_cols;
+            it.inner = (int32_t)d.inner;
+            it.lanes = L;
+            it.flags = vec ? 1 : 0;
+            it.pad_ = 0;
+        }
+    }
+    return n;
+}
+
+extern "C" int spice_gather_run(const float *src_base, float *dst_base, const int64_t *idx_base,
+                                const spice_gather_item *d_items, int64_t n_items, void *stream) {
+    if (n_items < 0 || n_items > INT32_MAX) return SPICE_ERR_ARG;
+    if (n_items == 0) return SPICE_OK;
+    if (!src_base || !dst_base || !d_items) return SPICE_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(src_base) & 3u) || (reinterpret_cast<uintptr_t>(dst_base) & 3u))
+        return SPICE_ERR_ARG;
+    const int vec_ok = aligned16(src_base) && aligned16(dst_base);
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)n_items), dim3(kGatherThreads), 0,
+                       static_cast<hipStream_t>(stream), reinterpret_cast<const unsigned *>(src_base),
+                       reinterpret_cast<unsigned *>(dst_base),
+                       reinterpret_cast<const long long *>(idx_base), d_items, vec_ok);
+    SPICE_LAUNCH_CHECK();
+    return SPICE_OK;
+}

@@ -1,0 +1,529 @@
+// Kernel (2): fused KD-Lite loss.  One coalesced pass over the student and teacher logits
+// ([N,C,H,W] fp32, class stride H*W) computes, per pixel, the temperature-softmax KL term,
+// the cross-entropy term and (optionally) d(loss)/d(student); all softmax statistics are kept
+// in registers by an online (running-maximum) formulation, so every logit is read once for the
+// loss (and once more, L2/MALL-warm, when the gradient is requested).
+//
+// Per pixel, with k = 1/T and centred logits  s'_c = s_c - max s,  t'_c = t_c - max t:
+//   Zs = sum exp(k s'_c)   Zt = sum exp(k t'_c)   Z1 = sum exp(s'_c)
+//   A  = sum exp(k t'_c) (t'_c - s'_c)
+//   KL(softmax(t/T) || softmax(s/T)) = k A / Zt - ln Zt + ln Zs
+//   nll = ln Z1 - s'_label
+// Sums over pixels are carried in fp64 from the thread level up and combined in a fixed
+// order (thread -> wave butterfly -> workgroup -> one finalising workgroup): deterministic.
+#include "common.h"
+
+namespace spice {
+
+constexpr int kKdThreads = 256;
+constexpr int kKdMaxBlocks = 2048;
+constexpr float kNegFill = -1.0e30f;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// workspace layout (bytes)
+constexpr size_t kKdOffBad = 0;       // int64: labels neither ignore_index nor in [0,C)
+constexpr size_t kKdOffTotals = 16;   // 8 doubles: the eight global sums
+constexpr size_t kKdOffPre = 128;     // kKdMaxBlocks x 4 doubles
+constexpr size_t kKdOffMain = kKdOffPre + (size_t)kKdMaxBlocks * 4 * 8;  // kKdMaxBlocks x 8 doubles
+constexpr size_t kKdWorkspace = kKdOffMain + (size_t)kKdMaxBlocks * 8 * 8;
+
+struct KdArgs {
+    const float *s;
+    const float *t;
+    const long long *labels;
+    float *grad;
+    const float *class_w;
+    const float *upstream;
+    double *pre_partial;
+    double *main_partial;
+    long long *bad;
+    long long N, HW;
+    int C, H, W;
+    int pre_blocks;
+    long long ignore_index;
+    float invT, T, alpha, bw, coef_ce, coef_kd;
+    int conf;
+};
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_ln(float x) { return __builtin_amdgcn_logf(x) * kLn2; }
+
+template <int VEC>
+struct VecF;
+template <>
+struct VecF<4> {
+    typedef float4 type;
+};
+template <>
+struct VecF<1> {
+    typedef float type;
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float *p, float (&v)[VEC]) {
+    if (VEC == 4) {
+        const float4 x = *reinterpret_cast<const float4 *>(p);
+        v[0] = x.x;
+        v[1 % VEC] = x.y;
+        v[2 % VEC] = x.z;
+        v[3 % VEC] = x.w;
+    } else {
+        v[0] = *p;
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float *p, const float (&v)[VEC]) {
+    if (VEC == 4) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]);
+    } else {
+        *p = v[0];
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_labels(const long long *p, long long (&v)[VEC]) {
+    if (VEC == 4) {
+        const longlong2 a = *reinterpret_cast<const longlong2 *>(p);
+        const longlong2 b = *reinterpret_cast<const longlong2 *>(p + 2);
+        v[0] = a.x;
+        v[1 % VEC] = a.y;
+        v[2 % VEC] = b.x;
+        v[3 % VEC] = b.y;
+    } else {
+        v[0] = *p;
+    }
+}
+
+// 3x3 dilate != erode on the label image (borders use in-bounds neighbours only).
+__device__ __forceinline__ bool label_boundary(const long long *img, long long pix, int H, int W) {
+    const int y = (int)(pix / W);
+    const int x = (int)(pix - (long long)y * W);
+    long long mn = img[pix], mx = mn;
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            const long long v = img[(long long)yy * W + xx];
+            mn = v < mn ? v : mn;
+            mx = v > mx ? v : mx;
+        }
+    }
+    return mn != mx;
+}
+
+// Sum `NQ` per-thread doubles over the workgroup; thread 0..NQ-1 of wave 0 end up holding the
+// totals in `out[k]` order.  red: [kKdThreads/64][8] doubles of LDS.
+template <int NQ>
+__device__ __forceinline__ void block_sum_store(const double (&acc)[NQ], double (*red)[8],
+                                                double *out) {
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        double v = 0.0;
+        for (int wv = 0; wv < kKdThreads / 64; ++wv) v += red[wv][threadIdx.x];
+        out[threadIdx.x] = v;
+    }
+}
+
+// Pre-pass (only when a gradient is requested): the loss normalisers, which depend on the
+// labels (and, for confidence weighting, on the teacher) but not on the student.
+// Per workgroup: {n_valid, sum class weight, n_boundary&valid, sum confidence&valid}.
+template <int VEC, bool EXT>
+__global__ __launch_bounds__(kKdThreads) void kdlite_prepass_kernel(KdArgs a) {
+    __shared__ double red[kKdThreads / 64][8];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const long long per_img = a.HW / VEC;
+    const long long total = a.N * per_img;
+    const bool use_b = EXT && a.bw > 1.0f;
+    const bool use_c = EXT && a.conf;
+    for (long long q = (long long)blockIdx.x * kKdThreads + threadIdx.x; q < total;
+         q += (long long)gridDim.x * kKdThreads) {
+        const long long n = q / per_img;
+        const long long r = (q - n * per_img) * VEC;
+        long long lab[VEC];
+        load_labels<VEC>(a.labels + n * a.HW + r, lab);
+        float zt1[VEC];
+        if (use_c) {
+            float mt[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                mt[e] = kNegFill;
+                zt1[e] = 0.f;
+            }
+            const float *tb = a.t + n * a.C * a.HW + r;
+            for (int c = 0; c < a.C; ++c) {
+                float tv[VEC];
+                load_vec<VEC>(tb + (long long)c * a.HW, tv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float mn = fmaxf(mt[e], tv[e]);
+                    zt1[e] = zt1[e] * fast_exp2((mt[e] - mn) * kLog2e) + fast_exp2((tv[e] - mn) * kLog2e);
+                    mt[e] = mn;
+                }
+            }
+        }
+        float nv = 0.f, ws = 0.f, nb = 0.f, cs = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const bool valid = lab[e] != a.ignore_index;
+            const bool inr = lab[e] >= 0 && lab[e] < a.C;
+            if (valid) nv += 1.f;
+            if (valid && inr) ws += a.class_w ? a.class_w[lab[e]] : 1.f;
+            if (use_b && valid && label_boundary(a.labels + n * a.HW, r + e, a.H, a.W)) nb += 1.f;
+            if (use_c && valid) cs += 1.f / zt1[e];
+        }
+        acc[0] += nv;
+        acc[1] += ws;
+        acc[2] += nb;
+        acc[3] += cs;
+    }
+    block_sum_store<4>(acc, red, a.pre_partial + (long long)blockIdx.x * 4);
+}
+
+template <int VEC, bool GRAD, bool EXT>
+__global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
+    __shared__ double red[kKdThreads / 64][8];
+    __shared__ double norm[4];
+    const int tid = threadIdx.x;
+    const bool use_b = EXT && a.bw > 1.0f;
+    const bool use_c = EXT && a.conf;
+    const float k2 = a.invT * kLog2e;  // exp(x/T) = exp2(x * k2)
+
+    float coef_ce = a.coef_ce, coef_kd = a.coef_kd;
+    float inv_nvalid = 0.f, inv_wsum = 0.f, inv_nb = 0.f, inv_cs = 0.f;
+    if (GRAD) {
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int b = tid; b < a.pre_blocks; b += kKdThreads) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += a.pre_partial[(long long)b * 4 + k];
+        }
+        block_sum_store<4>(v, red, norm);
+        __syncthreads();
+        inv_nvalid = norm[0] > 0.0 ? (float)(1.0 / norm[0]) : 0.f;
+        inv_wsum = norm[1] > 0.0 ? (float)(1.0 / norm[1]) : 0.f;
+        inv_nb = norm[2] > 0.0 ? (float)(1.0 / norm[2]) : 0.f;
+        inv_cs = norm[3] > 0.0 ? (float)(1.0 / norm[3]) : 0.f;
+        if (a.upstream) {
+            coef_ce = a.upstream[0] * a.alpha + a.upstream[1];
+            coef_kd = a.upstream[0] * (1.0f - a.alpha) + a.upstream[2];
+        }
+        __syncthreads();
+    }
+
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    long long bad = 0;
+    const long long per_img = a.HW / VEC;
+    const long long total = a.N * per_img;
+    const int C = a.C;
+    for (long long q = (long long)blockIdx.x * kKdThreads + tid; q < total;
+         q += (long long)gridDim.x * kKdThreads) {
+        const long long n = q / per_img;
+        const long long r = (q - n * per_img) * VEC;
+        const float *sb = a.s + n * C * a.HW + r;
+        const float *tb = a.t + n * C * a.HW + r;
+        long long lab[VEC];
+        load_labels<VEC>(a.labels + n * a.HW + r, lab);
+
+        float ms[VEC], mt[VEC], zs[VEC], z1[VEC], zt[VEC], zt1[VEC], at[VEC], sy[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            ms[e] = kNegFill;
+            mt[e] = kNegFill;
+            zs[e] = z1[e] = zt[e] = zt1[e] = at[e] = 0.f;
+            sy[e] = 0.f;
+        }
+        for (int c0 = 0; c0 < C; c0 += 4) {
+            float sv[4][VEC], tv[4][VEC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (c0 + u < C) {
+                    load_vec<VEC>(sb + (long long)(c0 + u) * a.HW, sv[u]);
+                    load_vec<VEC>(tb + (long long)(c0 + u) * a.HW, tv[u]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) sv[u][e] = tv[u][e] = kNegFill;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float msn = fmaxf(fmaxf(ms[e], fmaxf(sv[0][e], sv[1][e])), fmaxf(sv[2][e], sv[3][e]));
+                const float mtn = fmaxf(fmaxf(mt[e], fmaxf(tv[0][e], tv[1][e])), fmaxf(tv[2][e], tv[3][e]));
+                const float ds = ms[e] - msn;  // <= 0
+                const float dt = mt[e] - mtn;  // <= 0
+                const float rs = fast_exp2(ds * k2);
+                const float r1 = fast_exp2(ds * kLog2e);
+                const float rt = fast_exp2(dt * k2);
+                float Zs = zs[e] * rs, Z1 = z1[e] * r1;
+                float At = rt * (at[e] + zt[e] * (dt - ds));
+                float Zt = zt[e] * rt;
+                float Zt1 = 0.f;
+                if (use_c) Zt1 = zt1[e] * fast_exp2(dt * kLog2e);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float sc = sv[u][e] - msn;
+                    const float tc = tv[u][e] - mtn;
+                    const float et = fast_exp2(tc * k2);
+                    Zs += fast_exp2(sc * k2);
+                    Z1 += fast_exp2(sc * kLog2e);
+                    Zt += et;
+                    At += et * (tc - sc);
+                    if (use_c) Zt1 += fast_exp2(tc * kLog2e);
+                    if ((long long)(c0 + u) == lab[e]) sy[e] = sv[u][e];
+                }
+                ms[e] = msn;
+                mt[e] = mtn;
+                zs[e] = Zs;
+                z1[e] = Z1;
+                zt[e] = Zt;
+                at[e] = At;
+                zt1[e] = Zt1;
+            }
+        }
+
+        float wy[VEC], wkd[VEC];
+        float p_kl = 0.f, p_nv = 0.f, p_ce = 0.f, p_w = 0.f, p_bk = 0.f, p_nb = 0.f, p_ck = 0.f, p_cs = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const bool valid = lab[e] != a.ignore_index;
+            const bool inr = lab[e] >= 0 && lab[e] < C;
+            if (valid && !inr) ++bad;
+            const float kl = a.invT * at[e] / zt[e] - fast_ln(zt[e]) + fast_ln(zs[e]);
+            const float nll = fast_ln(z1[e]) - (sy[e] - ms[e]);
+            wy[e] = (valid && inr) ? (a.class_w ? a.class_w[lab[e]] : 1.f) : 0.f;
+            float wk = 0.f;
+            if (valid) {
+                p_kl += kl;
+                p_nv += 1.f;
+                wk = inv_nvalid;
+            }
+            if (wy[e] != 0.f) {
+                p_ce += wy[e] * nll;
+                p_w += wy[e];
+            }
+            if (use_b) {
+                if (valid && label_boundary(a.labels + n * a.HW, r + e, a.H, a.W)) {
+                    p_bk += kl;
+                    p_nb += 1.f;
+                    wk += (a.bw - 1.0f) * inv_nb;
+                }
+            }
+            if (use_c) {
+                const float cw = valid ? 1.f / zt1[e] : 0.f;
+                p_ck += cw * kl;
+                p_cs += cw;
+                wk = 0.5f * wk + 0.5f * cw * inv_cs;
+            }
+            wkd[e] = wk;
+        }
+        acc[0] += p_kl;
+        acc[1] += p_nv;
+        acc[2] += p_ce;
+        acc[3] += p_w;
+        if (EXT) {
+            acc[4] += p_bk;
+            acc[5] += p_nb;
+            acc[6] += p_ck;
+            acc[7] += p_cs;
+        }
+
+        if (GRAD) {
+            float gce[VEC], gkd[VEC], izs[VEC], iz1[VEC], izt[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                gce[e] = coef_ce * wy[e] * inv_wsum;
+                gkd[e] = coef_kd * a.T * wkd[e];  // T^2 * (1/T)
+                izs[e] = 1.f / zs[e];
+                iz1[e] = 1.f / z1[e];
+                izt[e] = 1.f / zt[e];
+            }
+            float *gb = a.grad + n * C * a.HW + r;
+#pragma unroll 2
+            for (int c = 0; c < C; ++c) {
+                float sv[VEC], tv[VEC], gv[VEC];
+                load_vec<VEC>(sb + (long long)c * a.HW, sv);
+                load_vec<VEC>(tb + (long long)c * a.HW, tv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float sc = sv[e] - ms[e];
+                    const float tc = tv[e] - mt[e];
+                    const float p1 = fast_exp2(sc * kLog2e) * iz1[e];
+                    const float ps = fast_exp2(sc * k2) * izs[e];
+                    const float pt = fast_exp2(tc * k2) * izt[e];
+                    const float onehot = ((long long)c == lab[e]) ? 1.f : 0.f;
+                    gv[e] = gce[e] * (p1 - onehot) + gkd[e] * (ps - pt);
+                }
+                store_vec<VEC>(gb + (long long)c * a.HW, gv);
+            }
+        }
+    }
+    if (bad) atomicAdd(reinterpret_cast<unsigned long long *>(a.bad), (unsigned long long)bad);
+    block_sum_store<8>(acc, red, a.main_partial + (long long)blockIdx.x * 8);
+}
+
+// One workgroup: fixed-order fp64 sum of the per-workgroup partials, then the scalar
+// epilogue of PixelKDLoss / CrossEntropyLoss / KDLiteLoss.
+__global__ __launch_bounds__(kKdThreads) void kdlite_finalize_kernel(const double *__restrict__ partial,
+                                                                      int n_blocks, double *totals,
+                                                                      float *out3, float T, float alpha,
+                                                                      float bw, int conf) {
+    __shared__ double red[kKdThreads / 64][8];
+    __shared__ double S[8];
+    double v[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < n_blocks; b += kKdThreads) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += partial[(long long)b * 8 + k];
+    }
+    block_sum_store<8>(v, red, S);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 8; ++k) totals[k] = S[k];
+        const double T2 = (double)T * (double)T;
+        double kd = S[1] > 0.0 ? S[0] / S[1] : 0.0;
+        kd *= T2;
+        if (bw > 1.0f) {
+            const double kb = S[5] > 0.0 ? S[4] / S[5] : 0.0;
+            kd += ((double)bw - 1.0) * (kb * T2);
+        }
+        if (conf) {
+            const double kc = S[7] > 0.0 ? S[6] / S[7] : 0.0;
+            kd = 0.5 * kd + 0.5 * (kc * T2);
+        }
+        const double ce = S[2] / S[3];  // 0/0 -> NaN, as CrossEntropyLoss with nothing to average
+        out3[0] = (float)((double)alpha * ce + (1.0 - (double)alpha) * kd);
+        out3[1] = (float)ce;
+        out3[2] = (float)kd;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_inplace_kernel(float *x, int64_t n, const float *scale) {
+    const float s = *scale;
+    if (s == 1.0f) return;
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) ? (n >> 2) : 0;
+    float4 *x4 = reinterpret_cast<float4 *>(x);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 v = x4[i];
+        v.x *= s;
+        v.y *= s;
+        v.z *= s;
+        v.w *= s;
+        x4[i] = v;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) x[i] *= s;
+}
+
+template <int VEC>
+static int kd_launch(const KdArgs &a, bool grad, bool ext, int blocks, hipStream_t st) {
+    const dim3 g(blocks), b(kKdThreads);
+    if (grad) {
+        if (ext)
+            hipLaunchKernelGGL((kdlite_prepass_kernel<VEC, true>), dim3(a.pre_blocks), b, 0, st, a);
+        else
+            hipLaunchKernelGGL((kdlite_prepass_kernel<VEC, false>), dim3(a.pre_blocks), b, 0, st, a);
+        SPICE_LAUNCH_CHECK();
+        if (ext)
+            hipLaunchKernelGGL((kdlite_main_kernel<VEC, true, true>), g, b, 0, st, a);
+        else
+            hipLaunchKernelGGL((kdlite_main_kernel<VEC, true, false>), g, b, 0, st, a);
+    } else {
+        if (ext)
+            hipLaunchKernelGGL((kdlite_main_kernel<VEC, false, true>), g, b, 0, st, a);
+        else
+            hipLaunchKernelGGL((kdlite_main_kernel<VEC, false, false>), g, b, 0, st, a);
+    }
+    SPICE_LAUNCH_CHECK();
+    return SPICE_OK;
+}
+
+}  // namespace spice
+
+using namespace spice;
+
+extern "C" size_t spice_kdlite_workspace_bytes(int64_t, int64_t, int64_t, int64_t) {
+    return kKdWorkspace;
+}
+
+extern "C" int spice_kdlite_forward(const float *student, const float *teacher, const int64_t *labels,
+                                    int64_t n, int64_t c, int64_t h, int64_t w,
+                                    const spice_kdlite_params *params, float *out3, float *grad,
+                                    float coef_ce, float coef_kd, const float *upstream,
+                                    void *workspace, size_t workspace_bytes, void *stream) {
+    if (!params || !out3 || !workspace) return SPICE_ERR_ARG;
+    if (n < 0 || c < 1 || h < 0 || w < 0) return SPICE_ERR_ARG;
+    if (c > INT32_MAX || h > INT32_MAX || w > INT32_MAX) return SPICE_ERR_UNSUPPORTED;
+    if (!(params->temperature > 0.f)) return SPICE_ERR_ARG;
+    if (workspace_bytes < kKdWorkspace) return SPICE_ERR_WORKSPACE;
+    if (!aligned16(workspace)) return SPICE_ERR_ARG;
+    const int64_t hw = h * w;
+    const int64_t pixels = n * hw;
+    if (pixels > 0 && (!student || !teacher || !labels)) return SPICE_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(student) & 3u) || (reinterpret_cast<uintptr_t>(teacher) & 3u) ||
+        (reinterpret_cast<uintptr_t>(grad) & 3u) || !aligned8(labels))
+        return SPICE_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace);
+
+    const bool ext = params->boundary_weight > 1.0f || params->confidence_weight != 0;
+    const bool vec4 = (hw % 4 == 0) && aligned16(student) && aligned16(teacher) && aligned16(labels) &&
+                      (grad == nullptr || aligned16(grad));
+    const int vec = vec4 ? 4 : 1;
+    int64_t blocks = ceil_div(pixels / vec, kKdThreads);
+    if (blocks < 1) blocks = 1;
+    if (blocks > kKdMaxBlocks) blocks = kKdMaxBlocks;
+
+    KdArgs a;
+    a.s = student;
+    a.t = teacher;
+    a.labels = reinterpret_cast<const long long *>(labels);
+    a.grad = grad;
+    a.class_w = params->class_weight;
+    a.upstream = upstream;
+    a.pre_partial = reinterpret_cast<double *>(ws + kKdOffPre);
+    a.main_partial = reinterpret_cast<double *>(ws + kKdOffMain);
+    a.bad = reinterpret_cast<long long *>(ws + kKdOffBad);
+    a.N = n;
+    a.HW = hw;
+    a.C = (int)c;
+    a.H = (int)h;
+    a.W = (int)w;
+    a.pre_blocks = (int)blocks;
+    a.ignore_index = params->ignore_index;
+    a.T = params->temperature;
+    a.invT = 1.0f / params->temperature;
+    a.alpha = params->alpha;
+    a.bw = params->boundary_weight;
+    a.coef_ce = coef_ce;
+    a.coef_kd = coef_kd;
+    a.conf = params->confidence_weight != 0;
+
+    const int rc = vec4 ? kd_launch<4>(a, grad != nullptr, ext, (int)blocks, st)
+                        : kd_launch<1>(a, grad != nullptr, ext, (int)blocks, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kdlite_finalize_kernel, dim3(1), dim3(kKdThreads), 0, st, a.main_partial,
+                       (int)blocks, reinterpret_cast<double *>(ws + kKdOffTotals), out3, a.T, a.alpha,
+                       a.bw, a.conf);
+    SPICE_LAUNCH_CHECK();
+    return SPICE_OK;
+}
+
+extern "C" int spice_scale_inplace(float *x, int64_t n, const float *scale, void *stream) {
+    if (n < 0) return SPICE_ERR_ARG;
+    if (n == 0) return SPICE_OK;
+    if (!x || !scale || (reinterpret_cast<uintptr_t>(x) & 3u)) return SPICE_ERR_ARG;
+    int64_t blocks = ceil_div(n, 256 * 16);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, n, scale);
+    SPICE_LAUNCH_CHECK();
+    return SPICE_OK;
+}

@@ -1,0 +1,407 @@
+"""Tensor-level entry points of the MI355X hot path.
+
+Each function validates its torch tensors, hands raw device pointers and the current
+HIP stream to the C ABI (spice_amd/_native.py) and returns torch tensors.  Nothing
+here computes on the CPU and nothing falls back to stock torch ops.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _native as nat
+
+# --------------------------------------------------------------------------------------
+# work-item tables
+
+
+def _upload_items(items, count: int, device: torch.device) -> torch.Tensor:
+    """Copy a ctypes array of `count` fixed-size records into a device byte tensor."""
+    nbytes = ctypes.sizeof(items._type_) * count
+    host = torch.empty(max(nbytes, 1), dtype=torch.uint8)
+    if nbytes:
+        ctypes.memmove(host.data_ptr(), ctypes.addressof(items), nbytes)
+    return host.to(device)
+
+
+@dataclass
+class RowsLayout:
+    """One weight tensor viewed as [rows, row_len], addressed by element offsets."""
+
+    w_off: int
+    g_off: int
+    out_off: int
+    rows: int
+    row_len: int
+
+
+class RowsPlan:
+    """Work-item table of the per-output-channel reduction for a fixed set of layers."""
+
+    def __init__(self, layers: Sequence[RowsLayout], device: torch.device):
+        L = nat.lib()
+        self.device = torch.device(device)
+        self.layers = list(layers)
+        descs = (nat.RowsDesc * max(len(self.layers), 1))()
+        for i, l in enumerate(self.layers):
+            descs[i] = nat.RowsDesc(l.w_off, l.g_off, l.out_off, l.rows, l.row_len)
+        n = L.spice_importance_plan(descs, len(self.layers), None, 0)
+        if n < 0:
+            nat.check(-n, "spice_importance_plan")
+        items = (nat.RowsItem * max(n, 1))()
+        got = L.spice_importance_plan(descs, len(self.layers), items, n)
+        assert got == n
+        self.n_items = int(n)
+        self.items = _upload_items(items, self.n_items, self.device)
+        self.weight_elems = sum(l.rows * l.row_len for l in self.layers)
+        self.score_elems = sum(l.rows for l in self.layers)
+
+    def run(self, w_base: int, g_base: int, score_base: int, mode: int, accumulate: bool) -> None:
+        rc = nat.lib().spice_importance_run(w_base, g_base, score_base, self.items.data_ptr(),
+                                            self.n_items, mode, int(bool(accumulate)),
+                                            nat.current_stream_ptr(self.device))
+        nat.check(rc, "spice_importance_run")
+
+    def algorithmic_bytes(self, mode: int) -> int:
+        """Bytes one launch must move: every weight (and gradient) element once plus the scores."""
+        if mode == nat.IMP_TAYLOR:
+            return 8 * self.weight_elems + 8 * self.score_elems
+        return 4 * self.weight_elems + 4 * self.score_elems
+
+
+@dataclass
+class ColsLayout:
+    w_off: int
+    out_off: int
+    rows: int
+    cols: int
+    inner: int
+
+
+class ColsPlan:
+    """Work-item tables of the per-input-channel reduction (two stages, fixed order)."""
+
+    def __init__(self, layers: Sequence[ColsLayout], device: torch.device):
+        L = nat.lib()
+        self.device = torch.device(device)
+        self.layers = list(layers)
+        nl = len(self.layers)
+        descs = (nat.ColsDesc * max(nl, 1))()
+        for i, l in enumerate(self.layers):
+            descs[i] = nat.ColsDesc(l.w_off, l.out_off, l.rows, l.cols, l.inner)
+        part = ctypes.c_int64(0)
+        n = L.spice_importance_cols_plan(descs, nl, None, 0, None, ctypes.byref(part))
+        if n < 0:
+            nat.check(-n, "spice_importance_cols_plan")
+        items = (nat.ColsItem * max(n, 1))()
+        folds = (nat.ColsFold * max(nl, 1))()
+        got = L.spice_importance_cols_plan(descs, nl, items, n, folds, ctypes.byref(part))
+        assert got == n
+        self.n_items, self.n_folds = int(n), nl
+        self.items = _upload_items(items, self.n_items, self.device)
+        self.folds = _upload_items(folds, self.n_folds, self.device)
+        self.partial = torch.empty(max(int(part.value), 4), dtype=torch.float32, device=self.device)
+
+    def run(self, w_base: int, score_base: int, mode: int) -> None:
+        rc = nat.lib().spice_importance_cols_run(w_base, score_base, self.partial.data_ptr(),
+                                                 self.items.data_ptr(), self.n_items,
+                                                 self.folds.data_ptr(), self.n_folds, mode,
+                                                 nat.current_stream_ptr(self.device))
+        nat.check(rc, "spice_importance_cols_run")
+
+
+def _relative_offsets(tensors: Sequence[torch.Tensor], what: str) -> Tuple[int, List[int]]:
+    """Base pointer (lowest address) and per-tensor element offsets from it."""
+    ptrs = [t.data_ptr() for t in tensors]
+    base = min(ptrs)
+    offs = []
+    for p in ptrs:
+        d = p - base
+        if d % 4:
+            raise ValueError(f"{what}: tensors are not 4-byte aligned relative to each other")
+        offs.append(d // 4)
+    return base, offs
+
+
+_rows_plan_cache: Dict[tuple, Tuple[RowsPlan, int, List[int]]] = {}
+
+
+def channel_importance(weights: Sequence[torch.Tensor], mode: int,
+                       grads: Optional[Sequence[torch.Tensor]] = None,
+                       out: Optional[torch.Tensor] = None, accumulate: bool = False
+                       ) -> Tuple[torch.Tensor, List[int]]:
+    """Per-output-channel reduction of every tensor in `weights` (viewed as [dim0, rest]).
+
+    mode: IMP_L1 (sum |w|), IMP_L2 (sum w^2) or IMP_TAYLOR (sum |g||w|, needs `grads`).
+    Returns (flat fp32 score vector, start offset of each tensor's scores in it).
+    One kernel launch covers all tensors.
+    """
+    if not weights:
+        raise ValueError("channel_importance: no tensors")
+    device = weights[0].device
+    for i, w in enumerate(weights):
+        nat.require_device_tensor(w, f"weights[{i}]", torch.float32)
+    if mode == nat.IMP_TAYLOR:
+        if grads is None or len(grads) != len(weights):
+            raise ValueError("channel_importance: Taylor mode needs one gradient per weight")
+        for i, (w, g) in enumerate(zip(weights, grads)):
+            nat.require_device_tensor(g, f"grads[{i}]", torch.float32)
+            if g.shape != w.shape:
+                raise ValueError(f"grads[{i}] shape {tuple(g.shape)} != weight {tuple(w.shape)}")
+    key = (mode == nat.IMP_TAYLOR, tuple((w.data_ptr(), tuple(w.shape)) for w in weights),
+           tuple(g.data_ptr() for g in grads) if mode == nat.IMP_TAYLOR else ())
+    hit = _rows_plan_cache.get(key)
+    if hit is None:
+        w_base, w_offs = _relative_offsets(weights, "weights")
+        if mode == nat.IMP_TAYLOR:
+            g_base, g_offs = _relative_offsets(grads, "grads")
+        else:
+            g_base, g_offs = 0, [0] * len(weights)
+        out_offs, pos = [], 0
+        layers = []
+        for w, wo, go in zip(weights, w_offs, g_offs):
+            rows = int(w.shape[0]) if w.dim() > 0 else 1
+            row_len = w.numel() // max(rows, 1)
+            layers.append(RowsLayout(wo, go, pos, rows, row_len))
+            out_offs.append(pos)
+            pos += rows
+        plan = RowsPlan(layers, device)
+        if len(_rows_plan_cache) > 64:
+            _rows_plan_cache.clear()
+        _rows_plan_cache[key] = (plan, w_base, g_base, out_offs)
+        hit = _rows_plan_cache[key]
+    plan, w_base, g_base, out_offs = hit
+    if out is None:
+        if accumulate:
+            raise ValueError("channel_importance: accumulate=True needs an existing `out`")
+        out = torch.empty(plan.score_elems, dtype=torch.float32, device=device)
+    else:
+        nat.require_device_tensor(out, "out", torch.float32)
+        if out.numel() != plan.score_elems:
+            raise ValueError(f"out has {out.numel()} elements, expected {plan.score_elems}")
+    plan.run(w_base, g_base, out.data_ptr(), mode, accumulate)
+    return out, out_offs
+
+
+# --------------------------------------------------------------------------------------
+# confusion matrix
+
+_workspaces: Dict[tuple, torch.Tensor] = {}
+
+
+def _workspace(kind: str, device: torch.device, nbytes: int) -> torch.Tensor:
+    """Per (kind, device, stream) scratch buffer, zero-initialised once."""
+    key = (kind, device.index, nat.current_stream_ptr(device))
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def confusion_update(conf: torch.Tensor, preds: torch.Tensor, target: torch.Tensor,
+                     num_classes: int) -> None:
+    """conf[t, p] += 1 for every pixel with 0 <= t < num_classes (in place, int64)."""
+    nat.require_device_tensor(conf, "conf", torch.int64)
+    nat.require_device_tensor(preds, "preds", torch.int64)
+    nat.require_device_tensor(target, "target", torch.int64)
+    if conf.shape != (num_classes, num_classes):
+        raise ValueError(f"conf must be [{num_classes},{num_classes}], got {tuple(conf.shape)}")
+    if preds.numel() != target.numel():
+        raise ValueError("preds and target differ in element count")
+    L = nat.lib()
+    n = preds.numel()
+    ws = _workspace("conf%d" % num_classes, conf.device,
+                    L.spice_confusion_workspace_bytes(n, num_classes))
+    rc = L.spice_confusion_update(preds.data_ptr(), target.data_ptr(), n, num_classes,
+                                  conf.data_ptr(), ws.data_ptr(), ws.numel(),
+                                  nat.current_stream_ptr(conf.device))
+    nat.check(rc, "spice_confusion_update")
+
+
+_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def argmax_confusion_update(conf: torch.Tensor, logits: torch.Tensor, target: torch.Tensor,
+                            num_classes: int) -> None:
+    """confusion_update(conf, logits.argmax(1), target) without materialising the arg-max."""
+    nat.require_device_tensor(conf, "conf", torch.int64)
+    nat.require_device_tensor(target, "target", torch.int64)
+    if logits.dtype not in _DTYPE_CODE:
+        raise TypeError(f"logits dtype {logits.dtype} not supported")
+    nat.require_device_tensor(logits, "logits", logits.dtype)
+    if logits.dim() < 2 or logits.shape[1] != num_classes:
+        raise ValueError("logits must be [N, num_classes, ...]")
+    n = int(logits.shape[0])
+    hw = logits.numel() // max(n * num_classes, 1)
+    if target.numel() != n * hw:
+        raise ValueError("target must have N*H*W elements")
+    L = nat.lib()
+    ws = _workspace("conf%d" % num_classes, conf.device,
+                    L.spice_confusion_workspace_bytes(n * hw, num_classes))
+    rc = L.spice_argmax_confusion_update(logits.data_ptr(), _DTYPE_CODE[logits.dtype],
+                                         target.data_ptr(), n, hw, num_classes, conf.data_ptr(),
+                                         ws.data_ptr(), ws.numel(),
+                                         nat.current_stream_ptr(conf.device))
+    nat.check(rc, "spice_argmax_confusion_update")
+
+
+def invalid_prediction_count(device: torch.device, num_classes: int) -> int:
+    """Pixels seen so far (this device and stream) whose prediction was outside [0, C).
+
+    Synchronises.  The reference fails on such input; here they are skipped and counted.
+    """
+    key = ("conf%d" % num_classes, torch.device(device).index,
+           nat.current_stream_ptr(torch.device(device)))
+    ws = _workspaces.get(key)
+    if ws is None:
+        return 0
+    return int(ws[:8].view(torch.int64).item())
+
+
+# --------------------------------------------------------------------------------------
+# KD-Lite loss
+
+
+def kdlite_forward(student: torch.Tensor, teacher: torch.Tensor, labels: torch.Tensor, *,
+                   temperature: float, alpha: float, ignore_index: int = 255,
+                   boundary_weight: float = 1.0, confidence_weight: bool = False,
+                   class_weight: Optional[torch.Tensor] = None, want_grad: bool = False,
+                   coef: Optional[Tuple[float, float]] = None,
+                   upstream: Optional[torch.Tensor] = None
+                   ) -> Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]:
+    """Fused KD-Lite loss.  Returns (out3 = [total, ce, kd], grad or None, sums[8] fp64).
+
+    grad = coef[0]*d(ce)/d(student) + coef[1]*d(kd)/d(student); coef defaults to
+    (alpha, 1-alpha), i.e. d(total)/d(student).  `upstream` (device, 3 floats: incoming
+    gradients of total/ce/kd) overrides coef on the device.
+    """
+    nat.require_device_tensor(student, "student_logits", torch.float32)
+    nat.require_device_tensor(teacher, "teacher_logits", torch.float32)
+    nat.require_device_tensor(labels, "labels", torch.int64)
+    if student.dim() != 4 or teacher.shape != student.shape:
+        raise ValueError("student/teacher logits must both be [N,C,H,W]")
+    n, c, h, w = (int(x) for x in student.shape)
+    if tuple(labels.shape) != (n, h, w):
+        raise ValueError(f"labels must be [{n},{h},{w}], got {tuple(labels.shape)}")
+    if class_weight is not None:
+        nat.require_device_tensor(class_weight, "class_weight", torch.float32)
+        if class_weight.numel() != c:
+            raise ValueError("class_weight must have C elements")
+    L = nat.lib()
+    dev = student.device
+    ws = _workspace("kdlite", dev, L.spice_kdlite_workspace_bytes(n, c, h, w))
+    out3 = torch.empty(3, dtype=torch.float32, device=dev)
+    grad = torch.empty_like(student) if want_grad else None
+    params = nat.KdliteParams(float(temperature), float(alpha), float(boundary_weight),
+                              int(bool(confidence_weight)), int(ignore_index),
+                              class_weight.data_ptr() if class_weight is not None else None)
+    cce, ckd = coef if coef is not None else (float(alpha), 1.0 - float(alpha))
+    if upstream is not None:
+        nat.require_device_tensor(upstream, "upstream", torch.float32)
+        if upstream.numel() != 3:
+            raise ValueError("upstream must have 3 elements")
+    rc = L.spice_kdlite_forward(student.data_ptr(), teacher.data_ptr(), labels.data_ptr(), n, c, h,
+                                w, ctypes.byref(params), out3.data_ptr(),
+                                grad.data_ptr() if grad is not None else None, cce, ckd,
+                                upstream.data_ptr() if upstream is not None else None,
+                                ws.data_ptr(), ws.numel(), nat.current_stream_ptr(dev))
+    nat.check(rc, "spice_kdlite_forward")
+    sums = ws[16:80].view(torch.float64)
+    return out3, grad, sums
+
+
+def kdlite_bad_label_count(device: torch.device) -> int:
+    """Labels seen so far (this device and stream) that were neither ignore_index nor in [0,C)."""
+    device = torch.device(device)
+    ws = _workspaces.get(("kdlite", device.index, nat.current_stream_ptr(device)))
+    return 0 if ws is None else int(ws[:8].view(torch.int64).item())
+
+
+def scale_inplace(x: torch.Tensor, scale: torch.Tensor) -> None:
+    """x *= scale (a device scalar); a no-op on the device when scale == 1."""
+    nat.require_device_tensor(x, "x", torch.float32)
+    nat.require_device_tensor(scale, "scale", torch.float32)
+    rc = nat.lib().spice_scale_inplace(x.data_ptr(), x.numel(), scale.data_ptr(),
+                                       nat.current_stream_ptr(x.device))
+    nat.check(rc, "spice_scale_inplace")
+
+
+# --------------------------------------------------------------------------------------
+# channel gather
+
+
+@dataclass
+class GatherSpec:
+    """dst[o,i,k] = src[keep_out[o], keep_in[i], k]; offsets in elements, -1 = keep all."""
+
+    src_off: int
+    dst_off: int
+    idx_out_off: int
+    idx_in_off: int
+    dst_rows: int
+    dst_cols: int
+    src_cols: int
+    inner: int
+
+
+class GatherPlan:
+    def __init__(self, specs: Sequence[GatherSpec], device: torch.device):
+        L = nat.lib()
+        self.device = torch.device(device)
+        self.specs = list(specs)
+        nt = len(self.specs)
+        descs = (nat.GatherDesc * max(nt, 1))()
+        for i, s in enumerate(self.specs):
+            descs[i] = nat.GatherDesc(s.src_off, s.dst_off, s.idx_out_off, s.idx_in_off,
+                                      s.dst_rows, s.dst_cols, s.src_cols, s.inner)
+        n = L.spice_gather_plan(descs, nt, None, 0)
+        if n < 0:
+            nat.check(-n, "spice_gather_plan")
+        items = (nat.GatherItem * max(n, 1))()
+        got = L.spice_gather_plan(descs, nt, items, n)
+        assert got == n
+        self.n_items = int(n)
+        self.items = _upload_items(items, self.n_items, self.device)
+        self.moved_elems = sum(s.dst_rows * s.dst_cols * s.inner for s in self.specs)
+        self.index_elems = sum((s.dst_rows if s.idx_out_off >= 0 else 0) +
+                               (s.dst_cols if s.idx_in_off >= 0 else 0) for s in self.specs)
+
+    def run(self, src_base: int, dst_base: int, idx_base: int) -> None:
+        rc = nat.lib().spice_gather_run(src_base, dst_base, idx_base, self.items.data_ptr(),
+                                        self.n_items, nat.current_stream_ptr(self.device))
+        nat.check(rc, "spice_gather_run")
+
+    def algorithmic_bytes(self) -> int:
+        return 8 * self.moved_elems + 8 * self.index_elems
+
+
+def gather_channels(src: torch.Tensor, keep_out: Optional[torch.Tensor],
+                    keep_in: Optional[torch.Tensor]) -> torch.Tensor:
+    """Single-tensor convenience: index_select on dim 0 and/or dim 1 in one pass."""
+    nat.require_device_tensor(src, "src", torch.float32)
+    rows = int(src.shape[0])
+    cols = int(src.shape[1]) if src.dim() > 1 else 1
+    inner = src.numel() // max(rows * cols, 1) if src.numel() else 1
+    idx_parts, o_off, i_off, pos = [], -1, -1, 0
+    d_rows, d_cols = rows, cols
+    if keep_out is not None:
+        nat.require_device_tensor(keep_out, "keep_out", torch.int64)
+        o_off, pos, d_rows = pos, pos + keep_out.numel(), keep_out.numel()
+        idx_parts.append(keep_out)
+    if keep_in is not None:
+        nat.require_device_tensor(keep_in, "keep_in", torch.int64)
+        i_off, pos, d_cols = pos, pos + keep_in.numel(), keep_in.numel()
+        idx_parts.append(keep_in)
+    idx = torch.cat(idx_parts) if idx_parts else torch.zeros(1, dtype=torch.int64, device=src.device)
+    shape = list(src.shape)
+    shape[0] = d_rows
+    if src.dim() > 1:
+        shape[1] = d_cols
+    dst = torch.empty(shape, dtype=torch.float32, device=src.device)
+    plan = GatherPlan([GatherSpec(0, 0, o_off, i_off, d_rows, d_cols, cols, max(inner, 1))], src.device)
+    plan.run(src.data_ptr(), dst.data_ptr(), idx.data_ptr())
+    return dst

@@ -172,6 +172,7 @@ def test_kdlite_config3_size(dev, variant):
         kw.update(boundary_weight=2.0, confidence_weight=True)
     out3, grad, sums = ops.kdlite_forward(torch.from_numpy(s).to(dev), torch.from_numpy(t).to(dev),
                                           torch.from_numpy(lab).to(dev), want_grad=True, **kw)
+    sums = sums.clone()  # a view of the per-stream workspace: the next call overwrites it
     got = out3.cpu().numpy()
     ref, g_ref = ok.kdlite_loss_and_grad(torch.from_numpy(s), torch.from_numpy(t), torch.from_numpy(lab),
                                          num_classes=c, **kw)

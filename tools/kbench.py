@@ -1,0 +1,137 @@
+"""Per-kernel micro-benchmark: HIP-event duration of every hot-path kernel at the benchmark
+sizes, cycling through enough distinct buffers to exceed the 256 MiB Infinity Cache.
+Usage: python tools/kbench.py [--iters 20] [--only name,...]"""
+import argparse
+import json
+import sys
+import os
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from spice_amd import _native as nat
+from spice_amd import ops, synth
+
+PEAK = 8000.0  # GB/s, MI355X HBM3E
+
+
+def timed(fn_list, iters, warmup=5):
+    """fn_list: callables cycled round-robin (one per rotating buffer set). Returns ms list."""
+    k = len(fn_list)
+    for i in range(warmup):
+        fn_list[i % k]()
+    torch.cuda.synchronize()
+    out = []
+    for i in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn_list[i % k]()
+        b.record()
+        b.synchronize()
+        out.append(a.elapsed_time(b))
+    return out
+
+
+def report(name, ms, nbytes):
+    med = float(np.median(ms))
+    gbs = nbytes / med / 1e6
+    print(json.dumps({"kernel": name, "ms_median": round(med, 4), "ms_min": round(min(ms), 4),
+                      "algorithmic_MB": round(nbytes / 1e6, 1), "GBps": round(gbs, 1),
+                      "frac_of_8TBps": round(gbs / PEAK, 3)}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", type=str, default="")
+    args = ap.parse_args()
+    only = set(x for x in args.only.split(",") if x)
+    dev = torch.device("cuda:0")
+    want = lambda n: not only or n in only
+
+    if want("importance") or want("taylor") or want("gather"):
+        shapes = synth.deeplab_resnet50_conv_shapes(21)
+        sizes = [o * i * kh * kw for o, i, kh, kw in shapes]
+        offs, pos = [], 0
+        for s in sizes:
+            offs.append(pos)
+            pos += (s + 3) // 4 * 4
+        total = pos
+        base = torch.from_numpy(synth.normal(1, 1, total)).to(dev)
+        layers, opos = [], 0
+        for (o, i, kh, kw), off in zip(shapes, offs):
+            layers.append(ops.RowsLayout(off, off, opos, o, i * kh * kw))
+            opos += o
+        plan = ops.RowsPlan(layers, dev)
+        copies = 4
+        ws = [base.clone() for _ in range(copies)]
+        gs = [base.clone() * 1e-3 for _ in range(copies)]
+        score = torch.zeros(opos, device=dev)
+        if want("importance"):
+            for mode, nm in ((nat.IMP_L2, "importance_l2"), (nat.IMP_L1, "importance_l1")):
+                fns = [lambda w=w: plan.run(w.data_ptr(), 0, score.data_ptr(), mode, False) for w in ws]
+                report(nm + f" ({plan.n_items} items)", timed(fns, args.iters), plan.algorithmic_bytes(mode))
+        if want("taylor"):
+            fns = [lambda w=w, g=g: plan.run(w.data_ptr(), g.data_ptr(), score.data_ptr(), nat.IMP_TAYLOR, True)
+                   for w, g in zip(ws, gs)]
+            report("importance_taylor", timed(fns, args.iters), plan.algorithmic_bytes(nat.IMP_TAYLOR))
+        if want("gather"):
+            specs, idx, dpos, ipos = [], [], 0, 0
+            for (o, i, kh, kw), off in zip(shapes, offs):
+                ko = np.arange(0, o, 2, dtype=np.int64)
+                specs.append(ops.GatherSpec(off, dpos, ipos, -1, len(ko), i, i, kh * kw))
+                idx.append(ko)
+                ipos += len(ko)
+                dpos += (len(ko) * i * kh * kw + 3) // 4 * 4
+            gplan = ops.GatherPlan(specs, dev)
+            idx_t = torch.from_numpy(np.concatenate(idx)).to(dev)
+            dsts = [torch.empty(dpos, device=dev) for _ in range(copies)]
+            fns = [lambda w=w, d=d: gplan.run(w.data_ptr(), d.data_ptr(), idx_t.data_ptr()) for w, d in zip(ws, dsts)]
+            report(f"gather_out50 ({gplan.n_items} items)", timed(fns, args.iters), gplan.algorithmic_bytes())
+        del ws, gs
+
+    if want("kdlite") or want("kdlite_grad"):
+        n, c, h, w = 8, 21, 512, 512
+        s, t = synth.logits_pair(1234, n, c, h, w)
+        lab = synth.label_map(1234, n, h, w, c)
+        sets = []
+        for k in range(2):
+            sets.append((torch.from_numpy(s).to(dev) + k, torch.from_numpy(t).to(dev) + k, torch.from_numpy(lab).to(dev).clone()))
+        P = n * h * w
+        if want("kdlite"):
+            fns = [lambda a=a: ops.kdlite_forward(a[0], a[1], a[2], temperature=4.0, alpha=0.7) for a in sets]
+            report("kdlite_fwd (incl. finalize)", timed(fns, args.iters), P * (2 * c * 4 + 8))
+            fns = [lambda a=a: ops.kdlite_forward(a[0], a[1], a[2], temperature=4.0, alpha=0.7, boundary_weight=2.0,
+                                                  confidence_weight=True) for a in sets]
+            report("kdlite_fwd_boundary_conf", timed(fns, args.iters), P * (2 * c * 4 + 8))
+        if want("kdlite_grad"):
+            fns = [lambda a=a: ops.kdlite_forward(a[0], a[1], a[2], temperature=4.0, alpha=0.7, want_grad=True) for a in sets]
+            report("kdlite_fwd_bwd (prepass+main+finalize, incl. grad alloc)", timed(fns, args.iters), P * (3 * c * 4 + 8))
+        del sets
+
+    if want("confusion"):
+        for (n, h, w, c, copies, tag) in ((8, 512, 512, 21, 10, "cfg1"), (32, 1024, 2048, 19, 1, "cfg5")):
+            for kind in ("uniform", "blocky"):
+                lab = synth.label_map(5, n, h, w, c, kind, ignore_share=0.10 if tag == "cfg5" else 0.05)
+                pred = synth.predictions_from(lab, 5, c)
+                tl, tp = torch.from_numpy(lab).to(dev), torch.from_numpy(pred).to(dev)
+                sets = [(tp.clone(), tl.clone()) for _ in range(copies)]
+                conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
+                fns = [lambda a=a: ops.confusion_update(conf, a[0], a[1], c) for a in sets]
+                report(f"confusion_{tag}_{kind} (hist+reduce)", timed(fns, args.iters), n * h * w * 16)
+                del sets
+
+    if want("argmax"):
+        n, c, h, w = 8, 21, 512, 512
+        s, _ = synth.logits_pair(1234, n, c, h, w)
+        lab = torch.from_numpy(synth.label_map(1234, n, h, w, c)).to(dev)
+        for dt, sz in ((torch.float32, 4), (torch.float16, 2)):
+            sets = [torch.from_numpy(s).to(dev).to(dt) + k for k in range(3)]
+            conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
+            fns = [lambda a=a: ops.argmax_confusion_update(conf, a, lab, c) for a in sets]
+            report(f"argmax_confusion_{str(dt)[6:]}", timed(fns, args.iters), n * h * w * (c * sz + 8))
+
+
+if __name__ == "__main__":
+    main()

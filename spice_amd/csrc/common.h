@@ -33,6 +33,26 @@ __device__ __forceinline__ float group_sum(float v, int width) {
     return v;
 }
 
+template <int W>
+__device__ __forceinline__ float group_sum_fixed(float v) {
+#pragma unroll
+    for (int o = W >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+// group_sum with the butterfly fully unrolled for the (wave-uniform) width.
+__device__ __forceinline__ float group_sum_sw(float v, int width) {
+    switch (width) {
+        case 64: return group_sum_fixed<64>(v);
+        case 32: return group_sum_fixed<32>(v);
+        case 16: return group_sum_fixed<16>(v);
+        case 8: return group_sum_fixed<8>(v);
+        case 4: return group_sum_fixed<4>(v);
+        case 2: return group_sum_fixed<2>(v);
+        default: return v;
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);

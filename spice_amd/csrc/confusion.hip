@@ -142,7 +142,12 @@ __global__ __launch_bounds__(256) void confusion_global_kernel(const long long *
     if (bad) atomicAdd(bad_total, bad);
 }
 
-// conf[b] += sum over workgroups of partial[g][b]; 64 bins x 8 slices per workgroup.
+// conf[b] += sum over workgroups of partial[g][b].  Grid (ceil(bins/64), kConfReduceY): a
+// workgroup sums its share of the partial rows for 64 bins (8 row slices per bin, combined in
+// LDS) and adds the result with one 64-bit atomic per bin; integer adds commute, so the result
+// does not depend on the order in which workgroups arrive.
+constexpr int kConfReduceY = 8;
+
 __global__ __launch_bounds__(512) void confusion_reduce_kernel(const unsigned *__restrict__ partial,
                                                                const unsigned *__restrict__ bad_partial,
                                                                int n_blocks, int bins,
@@ -152,26 +157,27 @@ __global__ __launch_bounds__(512) void confusion_reduce_kernel(const unsigned *_
     const int bl = threadIdx.x & 63;
     const int slice = threadIdx.x >> 6;
     const int b = blockIdx.x * 64 + bl;
+    const int step = 8 * gridDim.y;
     unsigned long long s = 0;
     if (b < bins) {
-        int g = slice;
-        for (; g + 24 < n_blocks; g += 32) {
+        int g = blockIdx.y * 8 + slice;
+        for (; g + 3 * step < n_blocks; g += 4 * step) {
             const unsigned v0 = partial[(int64_t)g * bins + b];
-            const unsigned v1 = partial[(int64_t)(g + 8) * bins + b];
-            const unsigned v2 = partial[(int64_t)(g + 16) * bins + b];
-            const unsigned v3 = partial[(int64_t)(g + 24) * bins + b];
+            const unsigned v1 = partial[(int64_t)(g + step) * bins + b];
+            const unsigned v2 = partial[(int64_t)(g + 2 * step) * bins + b];
+            const unsigned v3 = partial[(int64_t)(g + 3 * step) * bins + b];
             s += (unsigned long long)v0 + v1 + v2 + v3;
         }
-        for (; g < n_blocks; g += 8) s += partial[(int64_t)g * bins + b];
+        for (; g < n_blocks; g += step) s += partial[(int64_t)g * bins + b];
     }
     acc[slice][bl] = s;
     __syncthreads();
     if (slice == 0 && b < bins) {
         unsigned long long t = 0;
         for (int k = 0; k < 8; ++k) t += acc[k][bl];
-        conf[b] += (long long)t;
+        if (t) atomicAdd(reinterpret_cast<unsigned long long *>(conf) + b, t);
     }
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
         unsigned long long t = 0;
         for (int g = threadIdx.x; g < n_blocks; g += 64) t += bad_partial[g];
         t = (unsigned long long)wave_sum((double)t);  // exact: counts stay far below 2^53
@@ -338,7 +344,7 @@ extern "C" int spice_confusion_update(const int64_t *preds, const int64_t *targe
                        reinterpret_cast<const long long *>(target), n_pixels, (int)num_classes,
                        g.copies, g.stride, vec_ok, partial, bad_partial);
     SPICE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(confusion_reduce_kernel, dim3((unsigned)ceil_div(bins, 64)), dim3(512), 0, st,
+    hipLaunchKernelGGL(confusion_reduce_kernel, dim3((unsigned)ceil_div(bins, 64), kConfReduceY), dim3(512), 0, st,
                        partial, bad_partial, blocks, (int)bins, reinterpret_cast<long long *>(conf),
                        bad_total);
     SPICE_LAUNCH_CHECK();
@@ -371,7 +377,7 @@ extern "C" int spice_argmax_confusion_update(const void *logits, int32_t logits_
         rc = v4 ? launch_argmax<float, 4>(logits, target, n, hw, C, g, blocks, partial, bad_partial, st)
                 : launch_argmax<float, 1>(logits, target, n, hw, C, g, blocks, partial, bad_partial, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(confusion_reduce_kernel, dim3((unsigned)ceil_div(bins, 64)), dim3(512), 0,
+        hipLaunchKernelGGL(confusion_reduce_kernel, dim3((unsigned)ceil_div(bins, 64), kConfReduceY), dim3(512), 0,
                            st, partial, bad_partial, blocks, (int)bins,
                            reinterpret_cast<long long *>(conf), reinterpret_cast<long long *>(ws));
     } else {
@@ -386,7 +392,7 @@ extern "C" int spice_argmax_confusion_update(const void *logits, int32_t logits_
                     : launch_argmax<unsigned short, 1>(logits, target, n, hw, C, g, blocks, partial,
                                                        bad_partial, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(confusion_reduce_kernel, dim3((unsigned)ceil_div(bins, 64)), dim3(512), 0,
+        hipLaunchKernelGGL(confusion_reduce_kernel, dim3((unsigned)ceil_div(bins, 64), kConfReduceY), dim3(512), 0,
                            st, partial, bad_partial, blocks, (int)bins,
                            reinterpret_cast<long long *>(conf), reinterpret_cast<long long *>(ws));
     }

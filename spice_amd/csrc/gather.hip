@@ -81,7 +81,8 @@ extern "C" int64_t spice_gather_plan(const spice_gather_desc *tensors, int32_t n
         if (d.dst_rows == 0 || row_len == 0) continue;
         const bool vec = d.idx_in_off < 0 && (row_len % 4 == 0) && (d.src_off % 4 == 0) &&
                          (d.dst_off % 4 == 0);
-        const int64_t units = vec ? row_len / 4 : row_len;
+        // lanes per row: every lane should own at least four (vector) copies of its row
+        const int64_t units = (vec ? row_len / 4 : row_len) / 4;
         int L = kWave;
         while (L > 1 && L > units) L >>= 1;
         const int64_t groups = kGatherThreads / L;

@@ -4,10 +4,18 @@
 // then a butterfly over the lanes that share the row), so results are deterministic.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace spice {
 
 constexpr int kImpThreads = 256;
-constexpr int64_t kImpTargetElems = 16384;  // elements one work item (one workgroup) reduces
+constexpr int64_t kImpTargetElemsDefault = 16384;  // elements one work item (one workgroup) reduces
+
+static int64_t imp_target_elems() {
+    const char *e = getenv("SPICE_IMP_TARGET_ELEMS");  // tuning knob, read by the host planner only
+    const int64_t v = e ? atoll(e) : 0;
+    return v >= 1024 ? v : kImpTargetElemsDefault;
+}
 
 template <int MODE>
 __device__ __forceinline__ float imp_term(float w, float g) {
@@ -48,6 +56,17 @@ __global__ __launch_bounds__(kImpThreads) void importance_rows_kernel(
             const float4 *g4 = reinterpret_cast<const float4 *>(gr);
             const int K4 = K >> 2;
             int j = lane;
+            for (; j + 7 * L < K4; j += 8 * L) {
+                float4 x[8], y[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = w4[j + u * L];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) y[u] = (MODE == SPICE_IMP_TAYLOR) ? g4[j + u * L] : x[u];
+                a0 += imp_term4<MODE>(x[0], y[0]) + imp_term4<MODE>(x[4], y[4]);
+                a1 += imp_term4<MODE>(x[1], y[1]) + imp_term4<MODE>(x[5], y[5]);
+                a2 += imp_term4<MODE>(x[2], y[2]) + imp_term4<MODE>(x[6], y[6]);
+                a3 += imp_term4<MODE>(x[3], y[3]) + imp_term4<MODE>(x[7], y[7]);
+            }
             for (; j + 3 * L < K4; j += 4 * L) {
                 const float4 x0 = w4[j], x1 = w4[j + L], x2 = w4[j + 2 * L], x3 = w4[j + 3 * L];
                 float4 y0 = x0, y1 = x1, y2 = x2, y3 = x3;
@@ -90,7 +109,7 @@ __global__ __launch_bounds__(kImpThreads) void importance_rows_kernel(
                 a0 += imp_term<MODE>(x0, y0);
             }
         }
-        float s = group_sum((a0 + a1) + (a2 + a3), L);
+        float s = group_sum_sw((a0 + a1) + (a2 + a3), L);
         if (lane == 0) {
             if (accumulate) s += out[r];
             out[r] = s;
@@ -182,11 +201,12 @@ extern "C" int64_t spice_importance_plan(const spice_rows_desc *layers, int32_t 
         const int64_t K = d.row_len;
         const bool w_vec = (d.w_off % 4 == 0) && (K % 4 == 0) && K > 0;
         const bool g_vec = w_vec && (d.g_off % 4 == 0);
-        const int64_t units = w_vec ? K / 4 : K;
+        // lanes per row: every lane should own at least four (vector) loads of its row
+        const int64_t units = (w_vec ? K / 4 : K) / 4;
         int L = kWave;
         while (L > 1 && L > units) L >>= 1;
         const int64_t groups = kImpThreads / L;
-        int64_t rpi = K > 0 ? kImpTargetElems / K : d.rows;
+        int64_t rpi = K > 0 ? imp_target_elems() / K : d.rows;
         if (rpi < 1) rpi = 1;
         rpi = ceil_div(rpi, groups) * groups;
         const int64_t n_it = ceil_div(d.rows, rpi);

@@ -17,6 +17,7 @@ namespace spice {
 
 constexpr int kKdThreads = 256;
 constexpr int kKdMaxBlocks = 2048;
+constexpr int kKdFinalThreads = 1024;
 constexpr float kNegFill = -1.0e30f;
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
@@ -135,6 +136,35 @@ __device__ __forceinline__ void block_sum_store(const double (&acc)[NQ], double 
     }
 }
 
+// Work decomposition shared by the pre-pass and the main kernel: a tile is 256 consecutive
+// pixel groups (VEC pixels each) of ONE image, so the image index and every class-plane base
+// address are wave-uniform (scalar registers) and a lane only carries its 32-bit pixel offset.
+struct TileGeom {
+    int per_img;        // pixel groups per image = HW / VEC
+    int tiles_per_img;  // ceil(per_img / 256)
+    int n_tiles;        // N * tiles_per_img
+};
+
+template <int VEC>
+__device__ __forceinline__ TileGeom tile_geom(const KdArgs &a) {
+    TileGeom g;
+    g.per_img = (int)(a.HW / VEC);
+    g.tiles_per_img = (g.per_img + kKdThreads - 1) / kKdThreads;
+    g.n_tiles = (int)a.N * g.tiles_per_img;
+    return g;
+}
+
+// Labels as 32-bit class ids: >= 0 in range, -1 ignore_index, -2 any other out-of-range value.
+template <int VEC>
+__device__ __forceinline__ void load_label_ids(const long long *p, long long ignore_index, int C,
+                                               int (&id)[VEC]) {
+    long long lab[VEC];
+    load_labels<VEC>(p, lab);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+        id[e] = (lab[e] == ignore_index) ? -1 : ((lab[e] >= 0 && lab[e] < C) ? (int)lab[e] : -2);
+}
+
 // Pre-pass (only when a gradient is requested): the loss normalisers, which depend on the
 // labels (and, for confidence weighting, on the teacher) but not on the student.
 // Per workgroup: {n_valid, sum class weight, n_boundary&valid, sum confidence&valid}.
@@ -142,16 +172,17 @@ template <int VEC, bool EXT>
 __global__ __launch_bounds__(kKdThreads) void kdlite_prepass_kernel(KdArgs a) {
     __shared__ double red[kKdThreads / 64][8];
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    const long long per_img = a.HW / VEC;
-    const long long total = a.N * per_img;
+    const TileGeom tg = tile_geom<VEC>(a);
     const bool use_b = EXT && a.bw > 1.0f;
     const bool use_c = EXT && a.conf;
-    for (long long q = (long long)blockIdx.x * kKdThreads + threadIdx.x; q < total;
-         q += (long long)gridDim.x * kKdThreads) {
-        const long long n = q / per_img;
-        const long long r = (q - n * per_img) * VEC;
-        long long lab[VEC];
-        load_labels<VEC>(a.labels + n * a.HW + r, lab);
+    for (int tile = blockIdx.x; tile < tg.n_tiles; tile += gridDim.x) {
+        const int n = tile / tg.tiles_per_img;
+        const int qi = (tile - n * tg.tiles_per_img) * kKdThreads + (int)threadIdx.x;
+        if (qi >= tg.per_img) continue;
+        const int r = qi * VEC;
+        const long long *lab_img = a.labels + (long long)n * a.HW;
+        int id[VEC];
+        load_label_ids<VEC>(lab_img + r, a.ignore_index, a.C, id);
         float zt1[VEC];
         if (use_c) {
             float mt[VEC];
@@ -160,10 +191,10 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_prepass_kernel(KdArgs a) {
                 mt[e] = kNegFill;
                 zt1[e] = 0.f;
             }
-            const float *tb = a.t + n * a.C * a.HW + r;
+            const float *tb = a.t + (long long)n * a.C * a.HW;
             for (int c = 0; c < a.C; ++c) {
                 float tv[VEC];
-                load_vec<VEC>(tb + (long long)c * a.HW, tv);
+                load_vec<VEC>(tb + (long long)c * a.HW + r, tv);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     const float mn = fmaxf(mt[e], tv[e]);
@@ -175,11 +206,10 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_prepass_kernel(KdArgs a) {
         float nv = 0.f, ws = 0.f, nb = 0.f, cs = 0.f;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            const bool valid = lab[e] != a.ignore_index;
-            const bool inr = lab[e] >= 0 && lab[e] < a.C;
+            const bool valid = id[e] != -1;
             if (valid) nv += 1.f;
-            if (valid && inr) ws += a.class_w ? a.class_w[lab[e]] : 1.f;
-            if (use_b && valid && label_boundary(a.labels + n * a.HW, r + e, a.H, a.W)) nb += 1.f;
+            if (id[e] >= 0) ws += a.class_w ? a.class_w[id[e]] : 1.f;
+            if (use_b && valid && label_boundary(lab_img, r + e, a.H, a.W)) nb += 1.f;
             if (use_c && valid) cs += 1.f / zt1[e];
         }
         acc[0] += nv;
@@ -188,6 +218,106 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_prepass_kernel(KdArgs a) {
         acc[3] += cs;
     }
     block_sum_store<4>(acc, red, a.pre_partial + (long long)blockIdx.x * 4);
+}
+
+template <int VEC>
+struct PixStats {
+    float ms[VEC], mt[VEC], zs[VEC], z1[VEC], zt[VEC], zt1[VEC], at[VEC], sy[VEC];
+};
+
+// Fold four class planes (c0..c0+3) into the running softmax statistics of VEC pixels.
+// FULL = all four classes exist; otherwise loads are clamped to the last class and the
+// surplus values replaced by a large negative fill (their exponentials are exactly zero).
+template <int VEC, bool FULL, bool CONF>
+__device__ __forceinline__ void kd_fold4(PixStats<VEC> &st, const float *__restrict__ s_img,
+                                         const float *__restrict__ t_img, long long HW, int r,
+                                         int c0, int C, const int (&id)[VEC], float k2) {
+    float sv[4][VEC], tv[4][VEC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int cc = FULL ? c0 + u : min(c0 + u, C - 1);
+        load_vec<VEC>(s_img + (long long)cc * HW + r, sv[u]);
+        load_vec<VEC>(t_img + (long long)cc * HW + r, tv[u]);
+    }
+    if (!FULL) {
+#pragma unroll
+        for (int u = 1; u < 4; ++u) {
+            const bool gone = c0 + u >= C;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                sv[u][e] = gone ? kNegFill : sv[u][e];
+                tv[u][e] = gone ? kNegFill : tv[u][e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const float msn = fmaxf(fmaxf(st.ms[e], fmaxf(sv[0][e], sv[1][e])), fmaxf(sv[2][e], sv[3][e]));
+        const float mtn = fmaxf(fmaxf(st.mt[e], fmaxf(tv[0][e], tv[1][e])), fmaxf(tv[2][e], tv[3][e]));
+        const float ds = st.ms[e] - msn;  // <= 0
+        const float dt = st.mt[e] - mtn;  // <= 0
+        const float rt = fast_exp2(dt * k2);
+        float Zs = st.zs[e] * fast_exp2(ds * k2);
+        float Z1 = st.z1[e] * fast_exp2(ds * kLog2e);
+        float At = rt * (st.at[e] + st.zt[e] * (dt - ds));
+        float Zt = st.zt[e] * rt;
+        float Zt1 = 0.f;
+        if (CONF) Zt1 = st.zt1[e] * fast_exp2(dt * kLog2e);
+        float sy = st.sy[e];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float sc = sv[u][e] - msn;
+            const float tc = tv[u][e] - mtn;
+            const float et = fast_exp2(tc * k2);
+            Zs += fast_exp2(sc * k2);
+            Z1 += fast_exp2(sc * kLog2e);
+            Zt += et;
+            At += et * (tc - sc);
+            if (CONF) Zt1 += fast_exp2(tc * kLog2e);
+            sy = (c0 + u == id[e]) ? sv[u][e] : sy;
+        }
+        st.ms[e] = msn;
+        st.mt[e] = mtn;
+        st.zs[e] = Zs;
+        st.z1[e] = Z1;
+        st.zt[e] = Zt;
+        st.at[e] = At;
+        st.zt1[e] = Zt1;
+        st.sy[e] = sy;
+    }
+}
+
+// Gradient of four class planes: softmax probabilities recomputed from the final statistics.
+template <int VEC, bool FULL>
+__device__ __forceinline__ void kd_grad4(const PixStats<VEC> &st, const float *__restrict__ s_img,
+                                         const float *__restrict__ t_img, float *__restrict__ g_img,
+                                         long long HW, int r, int c0, int C, const int (&id)[VEC],
+                                         float k2, const float (&gce)[VEC], const float (&gkd)[VEC],
+                                         const float (&izs)[VEC], const float (&iz1)[VEC],
+                                         const float (&izt)[VEC]) {
+    float sv[4][VEC], tv[4][VEC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int cc = FULL ? c0 + u : min(c0 + u, C - 1);
+        load_vec<VEC>(s_img + (long long)cc * HW + r, sv[u]);
+        load_vec<VEC>(t_img + (long long)cc * HW + r, tv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (!FULL && c0 + u >= C) break;
+        float gv[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float sc = sv[u][e] - st.ms[e];
+            const float tc = tv[u][e] - st.mt[e];
+            const float p1 = fast_exp2(sc * kLog2e) * iz1[e];
+            const float ps = fast_exp2(sc * k2) * izs[e];
+            const float pt = fast_exp2(tc * k2) * izt[e];
+            const float onehot = (c0 + u == id[e]) ? 1.f : 0.f;
+            gv[e] = gce[e] * (p1 - onehot) + gkd[e] * (ps - pt);
+        }
+        store_vec<VEC>(g_img + (long long)(c0 + u) * HW + r, gv);
+    }
 }
 
 template <int VEC, bool GRAD, bool EXT>
@@ -220,105 +350,68 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
         __syncthreads();
     }
 
-    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    long long bad = 0;
-    const long long per_img = a.HW / VEC;
-    const long long total = a.N * per_img;
+    double acc[EXT ? 8 : 4];
+#pragma unroll
+    for (int k = 0; k < (EXT ? 8 : 4); ++k) acc[k] = 0.0;
+    int bad = 0;
+    const TileGeom tg = tile_geom<VEC>(a);
     const int C = a.C;
-    for (long long q = (long long)blockIdx.x * kKdThreads + tid; q < total;
-         q += (long long)gridDim.x * kKdThreads) {
-        const long long n = q / per_img;
-        const long long r = (q - n * per_img) * VEC;
-        const float *sb = a.s + n * C * a.HW + r;
-        const float *tb = a.t + n * C * a.HW + r;
-        long long lab[VEC];
-        load_labels<VEC>(a.labels + n * a.HW + r, lab);
+    const int C4 = C & ~3;
+    for (int tile = blockIdx.x; tile < tg.n_tiles; tile += gridDim.x) {
+        const int n = tile / tg.tiles_per_img;
+        const int qi = (tile - n * tg.tiles_per_img) * kKdThreads + tid;
+        if (qi >= tg.per_img) continue;
+        const int r = qi * VEC;
+        const float *s_img = a.s + (long long)n * C * a.HW;
+        const float *t_img = a.t + (long long)n * C * a.HW;
+        const long long *lab_img = a.labels + (long long)n * a.HW;
+        int id[VEC];
+        load_label_ids<VEC>(lab_img + r, a.ignore_index, C, id);
 
-        float ms[VEC], mt[VEC], zs[VEC], z1[VEC], zt[VEC], zt1[VEC], at[VEC], sy[VEC];
+        PixStats<VEC> st;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            ms[e] = kNegFill;
-            mt[e] = kNegFill;
-            zs[e] = z1[e] = zt[e] = zt1[e] = at[e] = 0.f;
-            sy[e] = 0.f;
+            st.ms[e] = st.mt[e] = kNegFill;
+            st.zs[e] = st.z1[e] = st.zt[e] = st.zt1[e] = st.at[e] = st.sy[e] = 0.f;
         }
-        for (int c0 = 0; c0 < C; c0 += 4) {
-            float sv[4][VEC], tv[4][VEC];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (c0 + u < C) {
-                    load_vec<VEC>(sb + (long long)(c0 + u) * a.HW, sv[u]);
-                    load_vec<VEC>(tb + (long long)(c0 + u) * a.HW, tv[u]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) sv[u][e] = tv[u][e] = kNegFill;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float msn = fmaxf(fmaxf(ms[e], fmaxf(sv[0][e], sv[1][e])), fmaxf(sv[2][e], sv[3][e]));
-                const float mtn = fmaxf(fmaxf(mt[e], fmaxf(tv[0][e], tv[1][e])), fmaxf(tv[2][e], tv[3][e]));
-                const float ds = ms[e] - msn;  // <= 0
-                const float dt = mt[e] - mtn;  // <= 0
-                const float rs = fast_exp2(ds * k2);
-                const float r1 = fast_exp2(ds * kLog2e);
-                const float rt = fast_exp2(dt * k2);
-                float Zs = zs[e] * rs, Z1 = z1[e] * r1;
-                float At = rt * (at[e] + zt[e] * (dt - ds));
-                float Zt = zt[e] * rt;
-                float Zt1 = 0.f;
-                if (use_c) Zt1 = zt1[e] * fast_exp2(dt * kLog2e);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float sc = sv[u][e] - msn;
-                    const float tc = tv[u][e] - mtn;
-                    const float et = fast_exp2(tc * k2);
-                    Zs += fast_exp2(sc * k2);
-                    Z1 += fast_exp2(sc * kLog2e);
-                    Zt += et;
-                    At += et * (tc - sc);
-                    if (use_c) Zt1 += fast_exp2(tc * kLog2e);
-                    if ((long long)(c0 + u) == lab[e]) sy[e] = sv[u][e];
-                }
-                ms[e] = msn;
-                mt[e] = mtn;
-                zs[e] = Zs;
-                z1[e] = Z1;
-                zt[e] = Zt;
-                at[e] = At;
-                zt1[e] = Zt1;
-            }
+        if (use_c) {
+#pragma unroll 1
+            for (int c0 = 0; c0 < C4; c0 += 4) kd_fold4<VEC, true, true>(st, s_img, t_img, a.HW, r, c0, C, id, k2);
+            if (C4 < C) kd_fold4<VEC, false, true>(st, s_img, t_img, a.HW, r, C4, C, id, k2);
+        } else {
+#pragma unroll 1
+            for (int c0 = 0; c0 < C4; c0 += 4) kd_fold4<VEC, true, false>(st, s_img, t_img, a.HW, r, c0, C, id, k2);
+            if (C4 < C) kd_fold4<VEC, false, false>(st, s_img, t_img, a.HW, r, C4, C, id, k2);
         }
 
         float wy[VEC], wkd[VEC];
         float p_kl = 0.f, p_nv = 0.f, p_ce = 0.f, p_w = 0.f, p_bk = 0.f, p_nb = 0.f, p_ck = 0.f, p_cs = 0.f;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            const bool valid = lab[e] != a.ignore_index;
-            const bool inr = lab[e] >= 0 && lab[e] < C;
-            if (valid && !inr) ++bad;
-            const float kl = a.invT * at[e] / zt[e] - fast_ln(zt[e]) + fast_ln(zs[e]);
-            const float nll = fast_ln(z1[e]) - (sy[e] - ms[e]);
-            wy[e] = (valid && inr) ? (a.class_w ? a.class_w[lab[e]] : 1.f) : 0.f;
+            const bool valid = id[e] != -1;
+            if (id[e] == -2) ++bad;
+            const float kl = a.invT * st.at[e] / st.zt[e] - fast_ln(st.zt[e]) + fast_ln(st.zs[e]);
+            const float nll = fast_ln(st.z1[e]) - (st.sy[e] - st.ms[e]);
+            wy[e] = (id[e] >= 0) ? (a.class_w ? a.class_w[id[e]] : 1.f) : 0.f;
             float wk = 0.f;
             if (valid) {
                 p_kl += kl;
                 p_nv += 1.f;
                 wk = inv_nvalid;
             }
-            if (wy[e] != 0.f) {
+            if (id[e] >= 0) {
                 p_ce += wy[e] * nll;
                 p_w += wy[e];
             }
             if (use_b) {
-                if (valid && label_boundary(a.labels + n * a.HW, r + e, a.H, a.W)) {
+                if (valid && label_boundary(lab_img, r + e, a.H, a.W)) {
                     p_bk += kl;
                     p_nb += 1.f;
                     wk += (a.bw - 1.0f) * inv_nb;
                 }
             }
             if (use_c) {
-                const float cw = valid ? 1.f / zt1[e] : 0.f;
+                const float cw = valid ? 1.f / st.zt1[e] : 0.f;
                 p_ck += cw * kl;
                 p_cs += cw;
                 wk = 0.5f * wk + 0.5f * cw * inv_cs;
@@ -330,10 +423,10 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
         acc[2] += p_ce;
         acc[3] += p_w;
         if (EXT) {
-            acc[4] += p_bk;
-            acc[5] += p_nb;
-            acc[6] += p_ck;
-            acc[7] += p_cs;
+            acc[4 % (EXT ? 8 : 4)] += p_bk;
+            acc[5 % (EXT ? 8 : 4)] += p_nb;
+            acc[6 % (EXT ? 8 : 4)] += p_ck;
+            acc[7 % (EXT ? 8 : 4)] += p_cs;
         }
 
         if (GRAD) {
@@ -342,48 +435,51 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
             for (int e = 0; e < VEC; ++e) {
                 gce[e] = coef_ce * wy[e] * inv_wsum;
                 gkd[e] = coef_kd * a.T * wkd[e];  // T^2 * (1/T)
-                izs[e] = 1.f / zs[e];
-                iz1[e] = 1.f / z1[e];
-                izt[e] = 1.f / zt[e];
+                izs[e] = 1.f / st.zs[e];
+                iz1[e] = 1.f / st.z1[e];
+                izt[e] = 1.f / st.zt[e];
             }
-            float *gb = a.grad + n * C * a.HW + r;
-#pragma unroll 2
-            for (int c = 0; c < C; ++c) {
-                float sv[VEC], tv[VEC], gv[VEC];
-                load_vec<VEC>(sb + (long long)c * a.HW, sv);
-                load_vec<VEC>(tb + (long long)c * a.HW, tv);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const float sc = sv[e] - ms[e];
-                    const float tc = tv[e] - mt[e];
-                    const float p1 = fast_exp2(sc * kLog2e) * iz1[e];
-                    const float ps = fast_exp2(sc * k2) * izs[e];
-                    const float pt = fast_exp2(tc * k2) * izt[e];
-                    const float onehot = ((long long)c == lab[e]) ? 1.f : 0.f;
-                    gv[e] = gce[e] * (p1 - onehot) + gkd[e] * (ps - pt);
-                }
-                store_vec<VEC>(gb + (long long)c * a.HW, gv);
-            }
+            float *g_img = a.grad + (long long)n * C * a.HW;
+#pragma unroll 1
+            for (int c0 = 0; c0 < C4; c0 += 4)
+                kd_grad4<VEC, true>(st, s_img, t_img, g_img, a.HW, r, c0, C, id, k2, gce, gkd, izs, iz1, izt);
+            if (C4 < C)
+                kd_grad4<VEC, false>(st, s_img, t_img, g_img, a.HW, r, C4, C, id, k2, gce, gkd, izs, iz1, izt);
         }
     }
     if (bad) atomicAdd(reinterpret_cast<unsigned long long *>(a.bad), (unsigned long long)bad);
-    block_sum_store<8>(acc, red, a.main_partial + (long long)blockIdx.x * 8);
+    double out8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out8[k] = (k < (EXT ? 8 : 4)) ? acc[k % (EXT ? 8 : 4)] : 0.0;
+    block_sum_store<8>(out8, red, a.main_partial + (long long)blockIdx.x * 8);
 }
 
 // One workgroup: fixed-order fp64 sum of the per-workgroup partials, then the scalar
 // epilogue of PixelKDLoss / CrossEntropyLoss / KDLiteLoss.
-__global__ __launch_bounds__(kKdThreads) void kdlite_finalize_kernel(const double *__restrict__ partial,
+__global__ __launch_bounds__(kKdFinalThreads) void kdlite_finalize_kernel(const double *__restrict__ partial,
                                                                       int n_blocks, double *totals,
                                                                       float *out3, float T, float alpha,
                                                                       float bw, int conf) {
-    __shared__ double red[kKdThreads / 64][8];
+    // thread t owns quantity t % 8 of workgroups t/8, t/8 + 32, ...: coalesced, then an LDS tree
+    __shared__ double red[kKdFinalThreads];
     __shared__ double S[8];
-    double v[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int b = threadIdx.x; b < n_blocks; b += kKdThreads) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] += partial[(long long)b * 8 + k];
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    const int total = n_blocks * 8;
+    int i = threadIdx.x;
+    for (; i + 3 * kKdFinalThreads < total; i += 4 * kKdFinalThreads) {
+        v0 += partial[i];
+        v1 += partial[i + kKdFinalThreads];
+        v2 += partial[i + 2 * kKdFinalThreads];
+        v3 += partial[i + 3 * kKdFinalThreads];
     }
-    block_sum_store<8>(v, red, S);
+    for (; i < total; i += kKdFinalThreads) v0 += partial[i];
+    red[threadIdx.x] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    for (int half = kKdFinalThreads / 2; half >= 8; half >>= 1) {
+        if ((int)threadIdx.x < half) red[threadIdx.x] += red[threadIdx.x + half];
+        __syncthreads();
+    }
+    if (threadIdx.x < 8) S[threadIdx.x] = red[threadIdx.x];
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 0; k < 8; ++k) totals[k] = S[k];
@@ -477,7 +573,10 @@ extern "C" int spice_kdlite_forward(const float *student, const float *teacher, 
     const bool vec4 = (hw % 4 == 0) && aligned16(student) && aligned16(teacher) && aligned16(labels) &&
                       (grad == nullptr || aligned16(grad));
     const int vec = vec4 ? 4 : 1;
-    int64_t blocks = ceil_div(pixels / vec, kKdThreads);
+    if (hw > INT32_MAX - 4096) return SPICE_ERR_UNSUPPORTED;
+    const int64_t tiles = n * ceil_div(hw / vec, kKdThreads);
+    if (tiles > INT32_MAX) return SPICE_ERR_UNSUPPORTED;
+    int64_t blocks = tiles;
     if (blocks < 1) blocks = 1;
     if (blocks > kKdMaxBlocks) blocks = kKdMaxBlocks;
 
@@ -509,7 +608,7 @@ extern "C" int spice_kdlite_forward(const float *student, const float *teacher, 
     const int rc = vec4 ? kd_launch<4>(a, grad != nullptr, ext, (int)blocks, st)
                         : kd_launch<1>(a, grad != nullptr, ext, (int)blocks, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(kdlite_finalize_kernel, dim3(1), dim3(kKdThreads), 0, st, a.main_partial,
+    hipLaunchKernelGGL(kdlite_finalize_kernel, dim3(1), dim3(kKdFinalThreads), 0, st, a.main_partial,
                        (int)blocks, reinterpret_cast<double *>(ws + kKdOffTotals), out3, a.T, a.alpha,
                        a.bw, a.conf);
     SPICE_LAUNCH_CHECK();

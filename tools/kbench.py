@@ -45,6 +45,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--imp-targets", type=str, default="")
     args = ap.parse_args()
     only = set(x for x in args.only.split(",") if x)
     dev = torch.device("cuda:0")
@@ -65,6 +66,16 @@ def main():
             opos += o
         plan = ops.RowsPlan(layers, dev)
         copies = 4
+        if args.imp_targets:
+            w_t = [base.clone() for _ in range(copies)]
+            sc_t = torch.zeros(opos, device=dev)
+            for tgt in args.imp_targets.split(","):
+                os.environ["SPICE_IMP_TARGET_ELEMS"] = tgt
+                pl = ops.RowsPlan(layers, dev)
+                fns = [lambda w=w: pl.run(w.data_ptr(), 0, sc_t.data_ptr(), nat.IMP_L2, False) for w in w_t]
+                report(f"importance_l2 target={tgt} ({pl.n_items} items)", timed(fns, args.iters), pl.algorithmic_bytes(nat.IMP_L2))
+            os.environ.pop("SPICE_IMP_TARGET_ELEMS")
+            del w_t
         ws = [base.clone() for _ in range(copies)]
         gs = [base.clone() * 1e-3 for _ in range(copies)]
         score = torch.zeros(opos, device=dev)

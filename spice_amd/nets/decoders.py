@@ -1,0 +1,177 @@
+"""DeepLabV3+, U-Net and FPN decoders and the assembled segmentation models (the wiring of
+segmentation_models_pytorch 0.5.0: encoder -> decoder -> segmentation_head)."""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class SeparableConv2d(nn.Sequential):
+    def __init__(self, in_ch: int, out_ch: int, kernel: int, padding: int = 0, dilation: int = 1,
+                 bias: bool = True):
+        super().__init__(
+            nn.Conv2d(in_ch, in_ch, kernel, padding=padding, dilation=dilation, groups=in_ch, bias=False),
+            nn.Conv2d(in_ch, out_ch, 1, bias=bias))
+
+
+def _conv_bn_relu(conv: nn.Module, ch: int) -> nn.Sequential:
+    return nn.Sequential(conv, nn.BatchNorm2d(ch), nn.ReLU())
+
+
+class ASPPPooling(nn.Module):
+    def __init__(self, in_ch: int, out_ch: int):
+        super().__init__()
+        self.pool = nn.AdaptiveAvgPool2d(1)
+        self.conv = nn.Conv2d(in_ch, out_ch, 1, bias=False)
+        self.bn = nn.BatchNorm2d(out_ch)
+        self.relu = nn.ReLU()
+
+    def forward(self, x):
+        y = self.relu(self.bn(self.conv(self.pool(x))))
+        return F.interpolate(y, size=x.shape[-2:], mode="bilinear", align_corners=False)
+
+
+class ASPP(nn.Module):
+    def __init__(self, in_ch: int, out_ch: int, rates: Sequence[int], separable: bool = True):
+        super().__init__()
+        branches = [_conv_bn_relu(nn.Conv2d(in_ch, out_ch, 1, bias=False), out_ch)]
+        for r in rates:
+            conv = (SeparableConv2d(in_ch, out_ch, 3, padding=r, dilation=r, bias=False) if separable
+                    else nn.Conv2d(in_ch, out_ch, 3, padding=r, dilation=r, bias=False))
+            branches.append(_conv_bn_relu(conv, out_ch))
+        branches.append(ASPPPooling(in_ch, out_ch))
+        self.convs = nn.ModuleList(branches)
+        self.project = nn.Sequential(nn.Conv2d(len(branches) * out_ch, out_ch, 1, bias=False),
+                                     nn.BatchNorm2d(out_ch), nn.ReLU(), nn.Dropout(0.5))
+
+    def forward(self, x):
+        return self.project(torch.cat([b(x) for b in self.convs], dim=1))
+
+
+class DeepLabV3PlusDecoder(nn.Module):
+    def __init__(self, encoder_channels: Sequence[int], out_channels: int = 256,
+                 rates: Sequence[int] = (12, 24, 36), highres_channels: int = 48):
+        super().__init__()
+        self.aspp = nn.Sequential(
+            ASPP(encoder_channels[-1], out_channels, rates, separable=True),
+            SeparableConv2d(out_channels, out_channels, 3, padding=1, bias=False),
+            nn.BatchNorm2d(out_channels), nn.ReLU())
+        self.up = nn.UpsamplingBilinear2d(scale_factor=4)
+        self.block1 = _conv_bn_relu(nn.Conv2d(encoder_channels[2], highres_channels, 1, bias=False),
+                                    highres_channels)
+        self.block2 = _conv_bn_relu(
+            SeparableConv2d(highres_channels + out_channels, out_channels, 3, padding=1, bias=False),
+            out_channels)
+        self.out_channels = out_channels
+
+    def forward(self, features: List[torch.Tensor]):
+        deep = self.up(self.aspp(features[-1]))
+        high = self.block1(features[2])
+        return self.block2(torch.cat([deep, high], dim=1))
+
+
+class UnetDecoderBlock(nn.Module):
+    def __init__(self, in_ch: int, skip_ch: int, out_ch: int):
+        super().__init__()
+        self.conv1 = _conv_bn_relu(nn.Conv2d(in_ch + skip_ch, out_ch, 3, padding=1, bias=False), out_ch)
+        self.conv2 = _conv_bn_relu(nn.Conv2d(out_ch, out_ch, 3, padding=1, bias=False), out_ch)
+        self.has_skip = skip_ch > 0
+
+    def forward(self, x, skip=None):
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        if self.has_skip:
+            x = torch.cat([x, skip], dim=1)
+        return self.conv2(self.conv1(x))
+
+
+class UnetDecoder(nn.Module):
+    def __init__(self, encoder_channels: Sequence[int], decoder_channels: Sequence[int] = (256, 128, 64, 32, 16)):
+        super().__init__()
+        enc = list(encoder_channels[1:])[::-1]
+        in_chs = [enc[0]] + list(decoder_channels[:-1])
+        skip_chs = enc[1:] + [0]
+        self.blocks = nn.ModuleList(UnetDecoderBlock(i, s, o)
+                                    for i, s, o in zip(in_chs, skip_chs, decoder_channels))
+        self.out_channels = decoder_channels[-1]
+
+    def forward(self, features: List[torch.Tensor]):
+        feats = features[1:][::-1]
+        x = feats[0]
+        skips = feats[1:]
+        for i, block in enumerate(self.blocks):
+            x = block(x, skips[i] if i < len(skips) else None)
+        return x
+
+
+class FPNBlock(nn.Module):
+    def __init__(self, pyramid_ch: int, skip_ch: int):
+        super().__init__()
+        self.skip_conv = nn.Conv2d(skip_ch, pyramid_ch, 1)
+
+    def forward(self, x, skip):
+        return F.interpolate(x, scale_factor=2.0, mode="nearest") + self.skip_conv(skip)
+
+
+class Conv3x3GNReLU(nn.Module):
+    def __init__(self, in_ch: int, out_ch: int, upsample: bool):
+        super().__init__()
+        self.upsample = upsample
+        self.block = nn.Sequential(nn.Conv2d(in_ch, out_ch, 3, padding=1, bias=False),
+                                   nn.GroupNorm(32, out_ch), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        x = self.block(x)
+        if self.upsample:
+            x = F.interpolate(x, scale_factor=2.0, mode="bilinear", align_corners=True)
+        return x
+
+
+class FPNDecoder(nn.Module):
+    def __init__(self, encoder_channels: Sequence[int], pyramid_ch: int = 256, seg_ch: int = 128):
+        super().__init__()
+        enc = list(encoder_channels)[::-1][:4]
+        self.p5 = nn.Conv2d(enc[0], pyramid_ch, 1)
+        self.p4 = FPNBlock(pyramid_ch, enc[1])
+        self.p3 = FPNBlock(pyramid_ch, enc[2])
+        self.p2 = FPNBlock(pyramid_ch, enc[3])
+        blocks = []
+        for n_up in (3, 2, 1, 0):
+            layers = [Conv3x3GNReLU(pyramid_ch, seg_ch, upsample=bool(n_up))]
+            layers += [Conv3x3GNReLU(seg_ch, seg_ch, upsample=True) for _ in range(1, n_up)]
+            blocks.append(nn.Sequential(*layers))
+        self.seg_blocks = nn.ModuleList(blocks)
+        self.dropout = nn.Dropout2d(0.2)
+        self.out_channels = seg_ch
+
+    def forward(self, features: List[torch.Tensor]):
+        c2, c3, c4, c5 = features[-4:]
+        p5 = self.p5(c5)
+        p4 = self.p4(p5, c4)
+        p3 = self.p3(p4, c3)
+        p2 = self.p2(p3, c2)
+        maps = [b(p) for b, p in zip(self.seg_blocks, (p5, p4, p3, p2))]
+        return self.dropout(maps[0] + maps[1] + maps[2] + maps[3])
+
+
+class SegmentationHead(nn.Sequential):
+    def __init__(self, in_ch: int, classes: int, kernel: int, upsampling: int):
+        up = nn.UpsamplingBilinear2d(scale_factor=upsampling) if upsampling > 1 else nn.Identity()
+        super().__init__(nn.Conv2d(in_ch, classes, kernel, padding=kernel // 2), up, nn.Identity())
+
+
+class SegmentationModel(nn.Module):
+    """encoder -> decoder -> segmentation_head; the head's convolutions are never pruned
+    (pruning/models.py:75-101 looks them up under the attribute name `segmentation_head`)."""
+
+    def __init__(self, encoder: nn.Module, decoder: nn.Module, head: nn.Module, name: str):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+        self.segmentation_head = head
+        self.name = name
+
+    def forward(self, x):
+        return self.segmentation_head(self.decoder(self.encoder(x)))

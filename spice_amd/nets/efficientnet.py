@@ -1,0 +1,120 @@
+"""EfficientNet-B3 feature encoder (width 1.2, depth 1.4; symmetric padding, SiLU, SE from the
+block input width), the architecture timm 1.0.19 builds for "efficientnet_b3"."""
+from __future__ import annotations
+
+import math
+from typing import List
+
+import torch
+import torch.nn as nn
+
+
+def _round_channels(ch: float, divisor: int = 8) -> int:
+    new = max(divisor, int(ch + divisor / 2) // divisor * divisor)
+    if new < 0.9 * ch:
+        new += divisor
+    return new
+
+
+class SqueezeExcite(nn.Module):
+    def __init__(self, channels: int, reduced: int):
+        super().__init__()
+        self.conv_reduce = nn.Conv2d(channels, reduced, 1)
+        self.act1 = nn.SiLU(inplace=True)
+        self.conv_expand = nn.Conv2d(reduced, channels, 1)
+
+    def forward(self, x):
+        s = x.mean((2, 3), keepdim=True)
+        s = self.conv_expand(self.act1(self.conv_reduce(s)))
+        return x * torch.sigmoid(s)
+
+
+class DepthwiseSeparable(nn.Module):
+    def __init__(self, in_chs: int, out_chs: int, kernel: int, stride: int, dilation: int = 1):
+        super().__init__()
+        pad = (kernel // 2) * dilation
+        self.has_skip = stride == 1 and in_chs == out_chs
+        self.conv_dw = nn.Conv2d(in_chs, in_chs, kernel, stride, pad, dilation, groups=in_chs, bias=False)
+        self.bn1 = nn.BatchNorm2d(in_chs)
+        self.act1 = nn.SiLU(inplace=True)
+        self.se = SqueezeExcite(in_chs, max(1, round(in_chs * 0.25)))
+        self.conv_pw = nn.Conv2d(in_chs, out_chs, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(out_chs)
+
+    def forward(self, x):
+        y = self.act1(self.bn1(self.conv_dw(x)))
+        y = self.bn2(self.conv_pw(self.se(y)))
+        return y + x if self.has_skip else y
+
+
+class InvertedResidual(nn.Module):
+    def __init__(self, in_chs: int, out_chs: int, kernel: int, stride: int, expand: int = 6,
+                 dilation: int = 1):
+        super().__init__()
+        mid = in_chs * expand
+        pad = (kernel // 2) * dilation
+        self.has_skip = stride == 1 and in_chs == out_chs
+        self.conv_pw = nn.Conv2d(in_chs, mid, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(mid)
+        self.act1 = nn.SiLU(inplace=True)
+        self.conv_dw = nn.Conv2d(mid, mid, kernel, stride, pad, dilation, groups=mid, bias=False)
+        self.bn2 = nn.BatchNorm2d(mid)
+        self.act2 = nn.SiLU(inplace=True)
+        self.se = SqueezeExcite(mid, max(1, round(in_chs * 0.25)))
+        self.conv_pwl = nn.Conv2d(mid, out_chs, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(out_chs)
+
+    def forward(self, x):
+        y = self.act1(self.bn1(self.conv_pw(x)))
+        y = self.act2(self.bn2(self.conv_dw(y)))
+        y = self.bn3(self.conv_pwl(self.se(y)))
+        return y + x if self.has_skip else y
+
+
+# (block type, repeats, out channels, kernel, stride) of EfficientNet-B0 before scaling
+_B0 = (("ds", 1, 16, 3, 1), ("ir", 2, 24, 3, 2), ("ir", 2, 40, 5, 2), ("ir", 3, 80, 3, 2),
+       ("ir", 3, 112, 5, 1), ("ir", 4, 192, 5, 2), ("ir", 1, 320, 3, 1))
+
+
+class EfficientNetB3Encoder(nn.Module):
+    """Returns [x, /2 (40), /4 (32), /8 (48), /16 (136), /32 or /16 (384)]."""
+
+    out_channels = (3, 40, 32, 48, 136, 384)
+
+    def __init__(self, in_channels: int = 3, output_stride: int = 32, width: float = 1.2,
+                 depth: float = 1.4):
+        super().__init__()
+        stem = _round_channels(32 * width)
+        self.conv_stem = nn.Conv2d(in_channels, stem, 3, stride=2, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(stem)
+        self.act1 = nn.SiLU(inplace=True)
+        stages = []
+        prev = stem
+        cur_stride, dilation = 2, 1
+        for kind, rep, ch, k, s in _B0:
+            out = _round_channels(ch * width)
+            blocks = []
+            for i in range(int(math.ceil(rep * depth))):
+                stride = s if i == 0 else 1
+                if stride > 1 and cur_stride >= output_stride:  # trade stride for dilation
+                    dilation *= stride
+                    stride = 1
+                cur_stride *= stride
+                d = dilation if (stride == 1 and dilation > 1) else 1
+                if kind == "ds":
+                    blocks.append(DepthwiseSeparable(prev, out, k, stride, d))
+                else:
+                    blocks.append(InvertedResidual(prev, out, k, stride, 6, d))
+                prev = out
+            stages.append(nn.Sequential(*blocks))
+        self.blocks = nn.Sequential(*stages)
+
+    def forward(self, x) -> List[torch.Tensor]:
+        f0 = x
+        f1 = self.act1(self.bn1(self.conv_stem(x)))
+        y = self.blocks[1](self.blocks[0](f1))
+        f2 = y
+        f3 = self.blocks[2](f2)
+        f4 = self.blocks[4](self.blocks[3](f3))
+        f5 = self.blocks[6](self.blocks[5](f4))
+        return [f0, f1, f2, f3, f4, f5]

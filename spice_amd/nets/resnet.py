@@ -1,0 +1,76 @@
+"""ResNet-50 feature encoder (torchvision layout, optionally dilated to output stride 16)."""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1, dilation: int = 1,
+                 downsample: bool = False):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation,
+                               bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if downsample:
+            self.downsample = nn.Sequential(
+                nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                nn.BatchNorm2d(planes * 4))
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return self.relu(out + identity)
+
+
+class ResNet50Encoder(nn.Module):
+    """Returns [x, /2 (64), /4 (256), /8 (512), /16 (1024), /32 or /16 (2048)]."""
+
+    out_channels = (3, 64, 256, 512, 1024, 2048)
+
+    def __init__(self, in_channels: int = 3, output_stride: int = 32):
+        super().__init__()
+        if output_stride not in (16, 32):
+            raise ValueError("output_stride must be 16 or 32")
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.inplanes = 64
+        self.layer1 = self._make_layer(64, 3, stride=1, dilation=1)
+        self.layer2 = self._make_layer(128, 4, stride=2, dilation=1)
+        self.layer3 = self._make_layer(256, 6, stride=2, dilation=1)
+        if output_stride == 16:  # stride of the last stage replaced by dilation 2
+            self.layer4 = self._make_layer(512, 3, stride=1, dilation=2)
+        else:
+            self.layer4 = self._make_layer(512, 3, stride=2, dilation=1)
+
+    def _make_layer(self, planes: int, blocks: int, stride: int, dilation: int) -> nn.Sequential:
+        layers = [Bottleneck(self.inplanes, planes, stride, dilation, downsample=True)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(Bottleneck(self.inplanes, planes, 1, dilation))
+        return nn.Sequential(*layers)
+
+    def forward(self, x) -> List[torch.Tensor]:
+        f0 = x
+        f1 = self.relu(self.bn1(self.conv1(x)))
+        f2 = self.layer1(self.maxpool(f1))
+        f3 = self.layer2(f2)
+        f4 = self.layer3(f3)
+        f5 = self.layer4(f4)
+        return [f0, f1, f2, f3, f4, f5]

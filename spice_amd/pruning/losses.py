@@ -1,0 +1,129 @@
+"""KD-Lite losses with the reference's module interface (pruning/losses.py:15-162), computed by
+the fused HIP kernel: one pass over the logits yields ce, kd and total (and, when the student
+needs a gradient, d(total)/d(student) in the same pass)."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+_FIVE_CLASS_WEIGHTS = (0.5, 1.0, 1.1, 1.5, 2.0)  # pruning/losses.py:66
+
+
+class _KDLiteFunction(torch.autograd.Function):
+    """(student, teacher, labels) -> (total, ce, kd).  The forward launch already writes the
+    gradient for upstream = (1, 0, 0); backward rescales it on the device, or recomputes with the
+    actual upstream gradients when ce / kd are differentiated on their own."""
+
+    @staticmethod
+    def forward(ctx, student, teacher, labels, opts):
+        want = student.requires_grad and torch.is_grad_enabled()
+        ctx.set_materialize_grads(False)
+        out3, grad, _ = ops.kdlite_forward(student.detach(), teacher.detach(), labels, want_grad=want, **opts)
+        ctx.opts = opts
+        ctx.saved_grad = grad
+        ctx.save_for_backward(student, teacher, labels)
+        return out3[0], out3[1], out3[2]
+
+    @staticmethod
+    def forward_nograd(student, teacher, labels, opts):
+        out3, _, _ = ops.kdlite_forward(student, teacher, labels, want_grad=False, **opts)
+        return out3[0], out3[1], out3[2]
+
+    @staticmethod
+    def backward(ctx, g_total, g_ce, g_kd):
+        student, teacher, labels = ctx.saved_tensors
+        if g_ce is None and g_kd is None:
+            if g_total is None:
+                return None, None, None, None
+            grad = ctx.saved_grad
+            if grad is None:  # forward ran without grad mode knowledge: recompute
+                _, grad, _ = ops.kdlite_forward(student.detach(), teacher.detach(), labels,
+                                                want_grad=True, **ctx.opts)
+            ops.scale_inplace(grad, g_total.reshape(1).float().contiguous())
+            ctx.saved_grad = None
+            return grad, None, None, None
+        zero = torch.zeros(1, device=student.device)
+        up = torch.cat([(g if g is not None else zero).reshape(1).float() for g in (g_total, g_ce, g_kd)])
+        _, grad, _ = ops.kdlite_forward(student.detach(), teacher.detach(), labels, want_grad=True,
+                                        upstream=up.contiguous(), **ctx.opts)
+        return grad, None, None, None
+
+
+def _prepare(logits: torch.Tensor) -> torch.Tensor:
+    if logits.dtype != torch.float32:
+        logits = logits.float()
+    return logits if logits.is_contiguous() else logits.contiguous()
+
+
+class KDLiteLoss(nn.Module):
+    """alpha * CE + (1 - alpha) * KD, optionally boundary- and confidence-weighted."""
+
+    def __init__(self, temperature: float = 4.0, alpha: float = 0.5, ignore_index: int = 255,
+                 boundary_weight: float = 1.0, confidence_weight: bool = False, num_classes: int = 5):
+        super().__init__()
+        self.temperature = temperature
+        self.alpha = alpha
+        self.ignore_index = ignore_index
+        self.boundary_weight = boundary_weight
+        self.confidence_weight = confidence_weight
+        self.num_classes = num_classes
+        self.ce_loss = SegmentationLoss(num_classes, ignore_index)
+        self.kd_loss = PixelKDLoss(temperature)
+
+    def forward(self, student_logits: torch.Tensor, teacher_logits: torch.Tensor,
+                labels: torch.Tensor) -> Dict[str, torch.Tensor]:
+        opts = dict(temperature=self.temperature, alpha=self.alpha, ignore_index=self.ignore_index,
+                    boundary_weight=self.boundary_weight, confidence_weight=self.confidence_weight,
+                    class_weight=self.ce_loss.class_weights)
+        total, ce, kd = _KDLiteFunction.apply(_prepare(student_logits), _prepare(teacher_logits),
+                                              labels.long().contiguous(), opts)
+        return {"total": total, "ce": ce, "kd": kd}
+
+
+class PixelKDLoss(nn.Module):
+    """T^2 * masked mean of KL(softmax(t/T) || softmax(s/T)) (pruning/losses.py:22-55)."""
+
+    def __init__(self, temperature: float = 4.0):
+        super().__init__()
+        self.temperature = temperature
+
+    def forward(self, student_logits: torch.Tensor, teacher_logits: torch.Tensor,
+                mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        n, _, h, w = student_logits.shape
+        if mask is None:
+            labels = torch.zeros(n, h, w, dtype=torch.int64, device=student_logits.device)
+        elif mask.dtype == torch.bool:
+            labels = torch.where(mask, 0, 255).to(torch.int64)
+        else:
+            raise NotImplementedError(
+                "PixelKDLoss with a float mask is only available through KDLiteLoss "
+                "(boundary_weight / confidence_weight)")
+        opts = dict(temperature=self.temperature, alpha=0.0, ignore_index=255)
+        _, _, kd = _KDLiteFunction.apply(_prepare(student_logits), _prepare(teacher_logits),
+                                         labels.contiguous(), opts)
+        return kd
+
+
+class SegmentationLoss(nn.Module):
+    """Cross-entropy with ignore_index and the 5-class weights (pruning/losses.py:58-84)."""
+
+    def __init__(self, num_classes: int = 5, ignore_index: int = 255):
+        super().__init__()
+        self.num_classes = num_classes
+        self.ignore_index = ignore_index
+        if num_classes == 5:
+            self.register_buffer("class_weights", torch.tensor(_FIVE_CLASS_WEIGHTS, dtype=torch.float))
+        else:
+            self.class_weights = None
+
+    def forward(self, predictions: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        opts = dict(temperature=1.0, alpha=1.0, ignore_index=self.ignore_index,
+                    class_weight=self.class_weights)
+        p = _prepare(predictions)
+        # alpha = 1: total == ce, and its gradient is the one the fused pass already wrote
+        total, _, _ = _KDLiteFunction.apply(p, p.detach(), targets.long().contiguous(), opts)
+        return total

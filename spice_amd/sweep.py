@@ -1,0 +1,141 @@
+"""Per-layer x pruning-ratio sensitivity sweep.
+
+A candidate = (channel group g, ratio r): remove the floor(r * C_g) least important channels of g
+(importance = the group magnitude criterion, ties to the lower index), evaluate the sliced model
+on one batch, and record (a) the mIoU confusion matrix against the labels and (b) the KD-Lite loss
+against the un-pruned model's logits.  Composed from the reference's primitives; the reference
+itself only runs the one-shot Taylor analysis (pruning/pruning_core.py:99-133).
+
+Per candidate the device sees: one gather launch (slice the group's tensors), the forward of the
+sliced network (MIOpen), one fused arg-max + histogram launch, one fused KD-Lite launch pair.
+Everything the host has to prepare (kept-index lists, launch plans) is built and uploaded for the
+whole sweep before the first candidate runs, so the candidate loop only enqueues work.
+Candidates are independent: ranks evaluate disjoint subsets and the [n_candidates, C, C] table
+is combined with one all-reduce.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import dist as sdist
+from . import ops
+from .engine import MagnitudeImportance, MagnitudePruner
+from .engine.pruner import SliceJob
+
+DEFAULT_RATIOS = (0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9)
+
+
+@dataclass
+class Candidate:
+    index: int
+    group: int          # index into SensitivitySweep.groups
+    ratio: float
+    pruned: np.ndarray  # channel ids removed from the group, ascending
+    cost: float         # relative cost estimate (for balancing ranks)
+
+
+class SensitivitySweep:
+    def __init__(self, model: nn.Module, num_classes: int, ratios: Sequence[float] = DEFAULT_RATIOS,
+                 importance=None, ignored_layers: Optional[Sequence[nn.Module]] = None,
+                 autocast_dtype: Optional[torch.dtype] = torch.float16,
+                 kd_temperature: float = 4.0, kd_alpha: float = 0.7):
+        self.model = model.eval()
+        self.num_classes = num_classes
+        self.autocast_dtype = autocast_dtype
+        self.kd = dict(temperature=kd_temperature, alpha=kd_alpha)
+        self.device = next(model.parameters()).device
+        self.importance = importance if importance is not None else MagnitudeImportance(p=2)
+        helper = MagnitudePruner(model, importance=self.importance, ignored_layers=ignored_layers)
+        self.groups = helper.prunable_groups()
+        # kernel (1): importance of every group from two launches over the whole model
+        self.group_importance = self.importance.batch(self.groups)
+        self.candidates: List[Candidate] = []
+        for gi, (g, imp) in enumerate(zip(self.groups, self.group_importance)):
+            if imp is None:
+                continue
+            order = np.argsort(imp, kind="stable")
+            seen = set()
+            for r in ratios:
+                n = int(r * g.size)
+                if n <= 0 or n >= g.size or n in seen:
+                    continue
+                seen.add(n)
+                self.candidates.append(Candidate(len(self.candidates), gi, float(r), np.sort(order[:n]),
+                                                 1.0 - 0.5 * r * g.size / max(g.size, 1)))
+        self.jobs: Dict[int, SliceJob] = {}
+
+    # -- host preparation for a set of candidates: plans + one shared index upload
+    def prepare(self, indices: Sequence[int]) -> None:
+        todo = [i for i in indices if i not in self.jobs]
+        jobs = [SliceJob([(self.groups[self.candidates[i].group], self.candidates[i].pruned)]) for i in todo]
+        arrays, starts, pos = [], [], 0
+        for j in jobs:
+            starts.append(pos)
+            for a in j.index_arrays():
+                arrays.append(a)
+                pos += len(a)
+        shared = (torch.from_numpy(np.concatenate(arrays)).to(self.device) if arrays else
+                  torch.zeros(1, dtype=torch.int64, device=self.device))
+        for i, j, st in zip(todo, jobs, starts):
+            self.jobs[i] = j.build(idx_device=shared, idx_start=st, with_grads=False)
+
+    def forward(self, images: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            if self.autocast_dtype is not None:
+                with torch.autocast("cuda", dtype=self.autocast_dtype):
+                    return self.model(images)
+            return self.model(images)
+
+    def evaluate(self, index: int, images: torch.Tensor, labels: torch.Tensor,
+                 teacher_logits: Optional[torch.Tensor], conf_out: torch.Tensor,
+                 kd_out: Optional[torch.Tensor] = None) -> int:
+        """Enqueue one candidate; conf_out [C,C] int64 (+=), kd_out [3] fp32 (=).  Returns the
+        algorithmic bytes of the gather launch."""
+        if index not in self.jobs:
+            self.prepare([index])
+        job = self.jobs[index]
+        moved = job.run(keep_undo=True)
+        try:
+            logits = self.forward(images).contiguous()
+            ops.argmax_confusion_update(conf_out, logits, labels, self.num_classes)
+            if teacher_logits is not None and kd_out is not None:
+                out3, _, _ = ops.kdlite_forward(logits.float(), teacher_logits, labels, **self.kd)
+                kd_out.copy_(out3)
+        finally:
+            job.undo()
+        return moved
+
+    def run(self, images: torch.Tensor, labels: torch.Tensor, indices: Optional[Sequence[int]] = None,
+            with_kd: bool = True) -> Dict[str, torch.Tensor]:
+        """Evaluate this rank's share of `indices` (default: all) and combine over ranks.
+        Returns {"confusion": [n,C,C] int64, "kd": [n,3] fp32, "miou": [n] fp64} (device tensors)."""
+        n = len(self.candidates)
+        indices = list(range(n)) if indices is None else list(indices)
+        rank, world = sdist.world()
+        parts = sdist.partition_by_cost([self.candidates[i].cost for i in indices], world)
+        mine = [indices[k] for k in parts[rank]]
+        self.prepare(mine)
+        c = self.num_classes
+        table = torch.zeros(n, c, c, dtype=torch.int64, device=self.device)
+        kd = torch.zeros(n, 3, dtype=torch.float32, device=self.device)
+        teacher = self.forward(images).float().contiguous() if with_kd else None
+        for i in mine:
+            self.evaluate(i, images, labels, teacher, table[i], kd[i] if with_kd else None)
+        sdist.all_reduce_sum_(table)
+        if with_kd:
+            sdist.all_reduce_sum_(kd)
+        return {"confusion": table, "kd": kd, "miou": miou_from_confusion(table)}
+
+
+def miou_from_confusion(table: torch.Tensor) -> torch.Tensor:
+    """mean over ALL classes of diag / (row + col - diag + 1e-10), per table (the in-tree
+    definition: baseline/eval/metrics.py:29-36), in fp64 on the device."""
+    m = table.double()
+    hit = torch.diagonal(m, dim1=-2, dim2=-1)
+    union = m.sum(-1) + m.sum(-2) - hit
+    return (hit / (union + 1e-10)).mean(-1)

@@ -1,0 +1,109 @@
+"""The pruning engine on the GPU (HIP importance + gather kernels under a `.step()`) against the
+CPU oracle's whole-step restatement, plus the drop-in surfaces built on it."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import prune_ref
+from spice_amd import engine, nets
+from spice_amd.engine.depgraph import build_groups
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _make(arch, enc, classes=7, seed=0):
+    torch.manual_seed(seed)
+    m = nets.create_model(arch, enc, classes)
+    # non-trivial BatchNorm scales so that they matter in the group importance
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5)
+                mod.running_mean.normal_(0, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+    return m.eval()
+
+
+def _ignored(m):
+    return [x for x in m.segmentation_head.modules() if isinstance(x, nn.Conv2d)]
+
+
+def _compare_models(gpu_model, cpu_model):
+    sd_g, sd_c = gpu_model.state_dict(), cpu_model.state_dict()
+    assert sd_g.keys() == sd_c.keys()
+    for k in sd_g:
+        a, b = sd_g[k].cpu(), sd_c[k]
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        if a.dtype == torch.float32:
+            assert np.array_equal(a.numpy().view(np.uint32), b.numpy().view(np.uint32)), k
+
+
+@pytest.mark.parametrize("arch,enc", [("DeepLabV3Plus", "resnet50"), ("Unet", "timm-efficientnet-b3"),
+                                      ("Unet", "resnet50")])
+def test_local_steps_match_oracle(dev, arch, enc):
+    base = _make(arch, enc)
+    cpu = copy.deepcopy(base)
+    gpu = copy.deepcopy(base).to(dev)
+    steps, ratio = 2, 0.5
+    pruner = engine.MagnitudePruner(gpu, importance=engine.MagnitudeImportance(p=2), pruning_ratio=ratio,
+                                    iterative_steps=steps, ignored_layers=_ignored(gpu), global_pruning=False)
+    cpu_groups = [g for g in build_groups(cpu) if not g.frozen]
+    init = {g.root: g.size for g in cpu_groups}
+    x = torch.randn(2, 3, 64, 64)
+    for step in range(1, steps + 1):
+        pruner.step()
+        prune_ref.step_local(cpu_groups, init, lambda g: ratio, step, steps, p=2)
+        _compare_models(gpu, cpu)
+        with torch.no_grad():
+            yg, yc = gpu(x.to(dev)).cpu(), cpu(x)
+        assert yg.shape == yc.shape == (2, 7, 64, 64)
+        assert torch.allclose(yg, yc, rtol=2e-3, atol=2e-3)
+    n0 = sum(p.numel() for p in base.parameters())
+    n1 = sum(p.numel() for p in gpu.parameters())
+    assert n1 < 0.45 * n0
+
+
+@pytest.mark.parametrize("arch,enc,p", [("DeepLabV3Plus", "resnet50", 2), ("Unet", "timm-efficientnet-b3", 1)])
+def test_global_step_matches_oracle(dev, arch, enc, p):
+    base = _make(arch, enc, seed=1)
+    cpu = copy.deepcopy(base)
+    gpu = copy.deepcopy(base).to(dev)
+    pruner = engine.MagnitudePruner(gpu, importance=engine.MagnitudeImportance(p=p), pruning_ratio=0.4,
+                                    iterative_steps=1, ignored_layers=_ignored(gpu), global_pruning=True)
+    cpu_groups = [g for g in build_groups(cpu) if not g.frozen]
+    total = sum(g.size for g in cpu_groups)
+    assert total == pruner.initial_total_channels
+    pruner.step()
+    prune_ref.step_global(cpu_groups, total, 0.4, 1, 1, p=p)
+    _compare_models(gpu, cpu)
+    x = torch.randn(1, 3, 64, 64)
+    with torch.no_grad():
+        assert torch.allclose(gpu(x.to(dev)).cpu(), cpu(x), rtol=2e-3, atol=2e-3)
+
+
+def test_ratio_dict_min_channels_and_gradients(dev):
+    gpu = _make("DeepLabV3Plus", "resnet50").to(dev)
+    conv = gpu.encoder.layer1[0].conv1
+    quotas = {conv: 0.75}
+    for p_ in gpu.parameters():
+        p_.grad = torch.ones_like(p_)
+    pruner = engine.MagnitudePruner(gpu, importance=engine.MagnitudeImportance(p=2), pruning_ratio=0.0,
+                                    pruning_ratio_dict=quotas, iterative_steps=1,
+                                    ignored_layers=_ignored(gpu), global_pruning=False)
+    pruner.step()
+    assert conv.out_channels == 16 and conv.weight.shape == (16, 64, 1, 1)
+    assert gpu.encoder.layer1[0].conv2.in_channels == 16
+    assert gpu.encoder.layer1[0].bn1.num_features == 16
+    assert conv.weight.grad is not None and conv.weight.grad.shape == conv.weight.shape
+    assert gpu.encoder.layer1[0].conv2.out_channels == 64  # ratio 0 everywhere else
+    with pytest.raises(IndexError):
+        pruner.step()

@@ -1,0 +1,297 @@
+"""Benchmark of the MI355X pruning hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload: the magnitude_taylor sensitivity sweep of DeepLabV3Plus_resnet on one synthetic
+21-class 8x3x512x512 evaluation batch.  One step = one sweep candidate per rank: slice one channel
+group at one ratio (HIP gather), forward the sliced network (MIOpen, fp16 autocast as the
+reference's evaluator), accumulate its mIoU confusion matrix (HIP fused arg-max histogram) and its
+KD-Lite loss against the un-pruned network's logits (HIP fused loss).  Weak scaling: every rank
+evaluates K candidates of its cost-balanced share; the per-candidate tables are combined with one
+all-reduce inside the timed region.  Set-up outside the timed region: model build, the Taylor
+calibration pass (HIP Taylor reduction) with quota allocation, group magnitude importance (HIP),
+launch plans.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from spice_amd import _native as nat  # noqa: E402
+from spice_amd import dist as sdist  # noqa: E402
+from spice_amd import nets, ops, synth  # noqa: E402
+from spice_amd.sweep import DEFAULT_RATIOS, SensitivitySweep  # noqa: E402
+
+PEAK_HBM_GBPS = 8000.0  # MI355X HBM3E peak
+CLASSES, BATCH, SIZE = 21, 8, 512
+
+
+def build_inputs(dev):
+    img = synth.normal(1234, 50, BATCH * 3 * SIZE * SIZE).reshape(BATCH, 3, SIZE, SIZE)
+    lab = synth.label_map(1234, BATCH, SIZE, SIZE, CLASSES, "blocky", ignore_share=0.05)
+    return torch.from_numpy(img).to(dev), torch.from_numpy(lab).to(dev)
+
+
+def taylor_and_quotas(model, images, labels, dev):
+    """The sensitivity analysis of the magnitude_taylor strategy: Taylor scores over calibration
+    batches (labels must be in [0,C): ignore pixels are mapped to class 0) and layer quotas."""
+    from spice_amd.pruning.pruner import LayerQuotaCalculator
+    from spice_amd.pruning.sensitivity_utils import compute_taylor_scores
+    cal = labels.clone()
+    cal[cal == 255] = 0
+    half = BATCH // 2
+    loader = [(images[:half], cal[:half]), (images[half:], cal[half:])]
+    t0 = time.perf_counter()
+    scores = compute_taylor_scores(model, loader, str(dev), max_batches=2)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+
+    class _Imp:
+        sensitivity_scores = scores
+
+    quotas, _ = LayerQuotaCalculator.compute_layer_quotas(model, _Imp, 0.5, alpha=0.7, min_channels=8)
+    return scores, quotas, t1 - t0
+
+
+def event_ms(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        times.append(a.elapsed_time(b))
+    return float(np.median(times))
+
+
+def kernel_table(dev):
+    """HIP-event time of every hand-written kernel at the benchmark sizes, cycling through more
+    than 256 MiB of distinct buffers so the Infinity Cache cannot serve repeats."""
+    out = []
+
+    def row(name, ms, nbytes):
+        gbs = nbytes / ms / 1e6
+        out.append({"kernel": name, "ms": round(ms, 4), "algorithmic_MB": round(nbytes / 1e6, 1),
+                    "GBps": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBPS, 3)})
+
+    shapes = synth.deeplab_resnet50_conv_shapes(CLASSES)
+    offs, pos = [], 0
+    for o, i, kh, kw in shapes:
+        offs.append(pos)
+        pos += (o * i * kh * kw + 3) // 4 * 4
+    layers, opos = [], 0
+    for (o, i, kh, kw), off in zip(shapes, offs):
+        layers.append(ops.RowsLayout(off, off, opos, o, i * kh * kw))
+        opos += o
+    plan = ops.RowsPlan(layers, dev)
+    ws = [torch.randn(pos, device=dev) * 0.05 for _ in range(4)]
+    gs = [torch.randn(pos, device=dev) * 1e-3 for _ in range(4)]
+    score = torch.zeros(opos, device=dev)
+    k = [0]
+
+    def cyc(lst):
+        k[0] += 1
+        return lst[k[0] % len(lst)]
+
+    row("importance_rows<L2> (DeepLabV3+-R50 conv weights)",
+        event_ms(lambda: plan.run(cyc(ws).data_ptr(), 0, score.data_ptr(), nat.IMP_L2, False), 20),
+        plan.algorithmic_bytes(nat.IMP_L2))
+    row("importance_rows<TAYLOR> (weights + grads, accumulate)",
+        event_ms(lambda: plan.run(cyc(ws).data_ptr(), gs[k[0] % 4].data_ptr(), score.data_ptr(),
+                                  nat.IMP_TAYLOR, True), 20),
+        plan.algorithmic_bytes(nat.IMP_TAYLOR))
+    specs, idx, dpos, ipos = [], [], 0, 0
+    for (o, i, kh, kw), off in zip(shapes, offs):
+        ko = np.arange(0, o, 2, dtype=np.int64)
+        specs.append(ops.GatherSpec(off, dpos, ipos, -1, len(ko), i, i, kh * kw))
+        idx.append(ko)
+        ipos += len(ko)
+        dpos += (len(ko) * i * kh * kw + 3) // 4 * 4
+    gplan = ops.GatherPlan(specs, dev)
+    idx_t = torch.from_numpy(np.concatenate(idx)).to(dev)
+    dsts = [torch.empty(dpos, device=dev) for _ in range(4)]
+    row("gather (keep every 2nd out-channel of every conv)",
+        event_ms(lambda: gplan.run(cyc(ws).data_ptr(), dsts[k[0] % 4].data_ptr(), idx_t.data_ptr()), 20),
+        gplan.algorithmic_bytes())
+    del ws, gs, dsts
+
+    sets = []
+    for j in range(2):
+        s = 3.0 * torch.randn(BATCH, CLASSES, SIZE, SIZE, device=dev)
+        sets.append((s, s + torch.randn_like(s), torch.randint(0, CLASSES, (BATCH, SIZE, SIZE), device=dev)))
+    P = BATCH * SIZE * SIZE
+    row("kdlite forward (T=4, alpha=0.7)",
+        event_ms(lambda: ops.kdlite_forward(*cyc(sets), temperature=4.0, alpha=0.7), 20), P * (2 * CLASSES * 4 + 8))
+    row("kdlite forward+grad (label pre-pass + fused pass)",
+        event_ms(lambda: ops.kdlite_forward(*cyc(sets), temperature=4.0, alpha=0.7, want_grad=True), 10),
+        P * (3 * CLASSES * 4 + 8))
+    lg16 = [s[0].half() for s in sets] + [sets[0][1].half()]
+    conf = torch.zeros(CLASSES, CLASSES, dtype=torch.int64, device=dev)
+    row("argmax+confusion fp16 logits",
+        event_ms(lambda: ops.argmax_confusion_update(conf, cyc(lg16), sets[0][2], CLASSES), 20),
+        P * (CLASSES * 2 + 8))
+    del lg16
+    small = [(torch.randint(0, CLASSES, (P,), device=dev), torch.randint(0, CLASSES, (P,), device=dev)) for _ in range(10)]
+    row("confusion [8,512,512] int64, 21 classes",
+        event_ms(lambda: ops.confusion_update(conf, *cyc(small), CLASSES), 20), P * 16)
+    del small, sets
+    P5 = 32 * 1024 * 2048
+    t5 = torch.randint(0, 19, (P5,), device=dev)
+    t5[torch.rand(P5, device=dev) < 0.1] = 255
+    p5 = torch.randint(0, 19, (P5,), device=dev)
+    conf5 = torch.zeros(19, 19, dtype=torch.int64, device=dev)
+    row("confusion [32,1024,2048] int64, 19 classes",
+        event_ms(lambda: ops.confusion_update(conf5, p5, t5, 19), 10), P5 * 16)
+    return out
+
+
+def cpu_candidate_baseline(model, sweep, images, labels):
+    """One sweep candidate through the CPU oracle on the host cores: group magnitude importance,
+    stable selection, index_select slicing, fp32 forward, arg-max, confusion, KD-Lite loss."""
+    import copy
+
+    from oracle import confusion as oc
+    from oracle import kdlite as ok
+    from oracle import prune_ref
+    from oracle import selection as osel
+    from spice_amd.engine.depgraph import build_groups
+
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    cpu_model = copy.deepcopy(model).cpu().float().eval()
+    x, y = images.cpu(), labels.cpu()
+    with torch.no_grad():
+        teacher = cpu_model(x)
+    cand = sweep.candidates[len(sweep.candidates) // 2]
+    root_name = sweep.groups[cand.group].root_name
+    groups = build_groups(cpu_model)
+    g = [gg for gg in groups if gg.root_name == root_name][0]
+    t0 = time.perf_counter()
+    imp = prune_ref.group_importance(g, 2)
+    pruned = osel.select_local(imp, len(cand.pruned))
+    prune_ref.prune_group(g, pruned)
+    with torch.no_grad():
+        logits = cpu_model(x)
+    conf = np.zeros((CLASSES, CLASSES), dtype=np.int64)
+    oc.update_confusion(conf, oc.argmax_first(logits.numpy()), y.numpy(), CLASSES)
+    ok.kdlite_loss(logits, teacher, y, temperature=4.0, alpha=0.7, num_classes=CLASSES)
+    dt = time.perf_counter() - t0
+    same = bool(np.array_equal(pruned, cand.pruned))
+    return {"value": round(1.0 / dt, 4), "unit": "candidates/s", "cores": cores, "kind": "port",
+            "sample": f"1 candidate (group {root_name}, ratio {cand.ratio}) on the same 8x3x512x512 batch: "
+                      f"oracle importance+selection+index_select slicing, fp32 torch-CPU forward, arg-max, "
+                      f"confusion, KD-Lite loss; {dt:.2f} s; selected channels equal to the HIP path: {same}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-table", action="store_true")
+    ap.add_argument("--fp32-forward", action="store_true", help="forward without fp16 autocast")
+    args = ap.parse_args()
+
+    rank, world, local = sdist.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    nat.lib()
+    torch.backends.cudnn.benchmark = False
+
+    torch.manual_seed(1234)
+    model = nets.create_model("DeepLabV3Plus", "resnet50", CLASSES).to(dev).eval()
+    images, labels = build_inputs(dev)
+    scores, quotas, taylor_s = taylor_and_quotas(model, images, labels, dev)
+    ignored = [m for m in model.segmentation_head.modules() if isinstance(m, torch.nn.Conv2d)]
+    sweep = SensitivitySweep(model, CLASSES, DEFAULT_RATIOS, ignored_layers=ignored,
+                             autocast_dtype=None if args.fp32_forward else torch.float16)
+    n_cand = len(sweep.candidates)
+    parts = sdist.partition_by_cost([c.cost for c in sweep.candidates], world)
+    mine = parts[rank]
+    total_steps = args.warmup + args.steps
+    todo = [mine[i % len(mine)] for i in range(total_steps)]
+    sweep.prepare(sorted(set(todo)))
+    teacher = sweep.forward(images).float().contiguous()
+    table = torch.zeros(n_cand, CLASSES, CLASSES, dtype=torch.int64, device=dev)
+    kd = torch.zeros(n_cand, 3, dtype=torch.float32, device=dev)
+
+    for i in range(args.warmup):
+        table[todo[i]].zero_()
+        sweep.evaluate(todo[i], images, labels, teacher, table[todo[i]], kd[todo[i]])
+    sweep.kd_events = []
+    sdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    moved = 0
+    for i in range(args.warmup, total_steps):
+        table[todo[i]].zero_()
+        moved += sweep.evaluate(todo[i], images, labels, teacher, table[todo[i]], kd[todo[i]])
+    sdist.all_reduce_sum_(table)
+    sdist.all_reduce_sum_(kd)
+    torch.cuda.synchronize()
+    sdist.barrier()
+    elapsed = time.perf_counter() - t0
+    kd_events = sweep.kd_events
+    sweep.kd_events = None
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    kd_ms = float(np.mean([a.elapsed_time(b) for a, b in kd_events])) if kd_events else float("nan")
+    kd_bytes = BATCH * SIZE * SIZE * (2 * CLASSES * 4 + 8)
+    achieved = kd_bytes / kd_ms / 1e6
+    result = {
+        "metric": "sensitivity-sweep candidates/sec",
+        "value": round(world * args.steps / elapsed, 3),
+        "unit": "candidates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "DeepLabV3Plus_resnet magnitude_taylor sensitivity sweep: one (channel group x "
+                               "ratio) candidate per step = gather + forward + arg-max/confusion + KD-Lite loss",
+                   "num_classes": CLASSES, "eval_batch": [BATCH, 3, SIZE, SIZE], "candidates": n_cand,
+                   "groups": len(sweep.groups), "ratios": list(DEFAULT_RATIOS),
+                   "forward": "fp32" if args.fp32_forward else "fp16 autocast (MIOpen)",
+                   "kd": {"T": 4.0, "alpha": 0.7}, "parallelism": f"candidates sharded over {world} rank(s)"},
+        "roofline": {"bound": "hbm", "kernel": "spice::kdlite_main_kernel<4,false,false> (one launch per "
+                     "spice_kdlite_forward call)", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS,
+                     "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": kd_bytes, "avg_launch_us": round(1e3 * kd_ms, 2),
+                     "launches_timed": len(kd_events)},
+        "setup": {"taylor_calibration_s": round(taylor_s, 3), "taylor_batches": 2,
+                  "quota_layers": len(quotas), "gather_MB_per_candidate": round(moved / max(args.steps, 1) / 1e6, 2)},
+    }
+    if rank == 0 and world == 1:
+        if not args.no_kernel_table:
+            result["kernels"] = kernel_table(dev)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_candidate_baseline(model, sweep, images, labels)
+            result["cpu_baseline"]["gpu_over_cpu"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -153,7 +153,9 @@ size_t spice_kdlite_workspace_bytes(int64_t n, int64_t c, int64_t h, int64_t w);
  * upstream[0]*(1-alpha) + upstream[2] and coef_ce/coef_kd are ignored.
  * The workspace's first int64 is incremented by the number of labels that are neither
  * ignore_index nor in [0,C) (the reference raises for them); such pixels contribute
- * nothing to ce.  The caller zeroes that word once after allocating the workspace.
+ * nothing to ce.  The caller zeroes the workspace once after allocating it (bytes [8,12)
+ * hold an arrival counter that every call returns to zero) and must not share one workspace
+ * between calls that may overlap in time (use one per stream).
  * Bytes [16,80) of the workspace receive the eight fp64 pixel sums of the call:
  * {sum valid*KL, n_valid, sum w*nll, sum w, sum boundary*KL, n_boundary,
  *  sum conf*KL, sum conf}. */

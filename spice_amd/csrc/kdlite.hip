@@ -16,14 +16,14 @@
 namespace spice {
 
 constexpr int kKdThreads = 256;
-constexpr int kKdMaxBlocks = 2048;
-constexpr int kKdFinalThreads = 1024;
+constexpr int kKdMaxBlocks = 1024;
 constexpr float kNegFill = -1.0e30f;
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
 // workspace layout (bytes)
 constexpr size_t kKdOffBad = 0;       // int64: labels neither ignore_index nor in [0,C)
+constexpr size_t kKdOffTicket = 8;    // uint32 arrival counter of the main kernel (returns to 0)
 constexpr size_t kKdOffTotals = 16;   // 8 doubles: the eight global sums
 constexpr size_t kKdOffPre = 128;     // kKdMaxBlocks x 4 doubles
 constexpr size_t kKdOffMain = kKdOffPre + (size_t)kKdMaxBlocks * 4 * 8;  // kKdMaxBlocks x 8 doubles
@@ -39,6 +39,9 @@ struct KdArgs {
     double *pre_partial;
     double *main_partial;
     long long *bad;
+    unsigned *ticket;
+    double *totals;
+    float *out3;
     long long N, HW;
     int C, H, W;
     int pre_blocks;
@@ -320,6 +323,50 @@ __device__ __forceinline__ void kd_grad4(const PixStats<VEC> &st, const float *_
     }
 }
 
+// Run by ONE workgroup of kKdThreads threads: fixed-order fp64 sum of the per-workgroup partials,
+// then the scalar epilogue of PixelKDLoss / CrossEntropyLoss / KDLiteLoss.
+__device__ __forceinline__ void kd_finalize(const double *partial, int n_blocks, double *totals,
+                                            float *out3, float T, float alpha, float bw, int conf) {
+    // thread t owns quantity t % 8 of workgroups t/8, t/8 + 32, ...: coalesced, then an LDS tree
+    __shared__ double fin_red[kKdThreads];
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    const int total = n_blocks * 8;
+    int i = threadIdx.x;
+    for (; i + 3 * kKdThreads < total; i += 4 * kKdThreads) {
+        v0 += partial[i];
+        v1 += partial[i + kKdThreads];
+        v2 += partial[i + 2 * kKdThreads];
+        v3 += partial[i + 3 * kKdThreads];
+    }
+    for (; i < total; i += kKdThreads) v0 += partial[i];
+    fin_red[threadIdx.x] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    for (int half = kKdThreads / 2; half >= 8; half >>= 1) {
+        if ((int)threadIdx.x < half) fin_red[threadIdx.x] += fin_red[threadIdx.x + half];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double S[8];
+        for (int k = 0; k < 8; ++k) S[k] = fin_red[k];
+        for (int k = 0; k < 8; ++k) totals[k] = S[k];
+        const double T2 = (double)T * (double)T;
+        double kd = S[1] > 0.0 ? S[0] / S[1] : 0.0;
+        kd *= T2;
+        if (bw > 1.0f) {
+            const double kb = S[5] > 0.0 ? S[4] / S[5] : 0.0;
+            kd += ((double)bw - 1.0) * (kb * T2);
+        }
+        if (conf) {
+            const double kc = S[7] > 0.0 ? S[6] / S[7] : 0.0;
+            kd = 0.5 * kd + 0.5 * (kc * T2);
+        }
+        const double ce = S[2] / S[3];  // 0/0 -> NaN, as CrossEntropyLoss with nothing to average
+        out3[0] = (float)((double)alpha * ce + (1.0 - (double)alpha) * kd);
+        out3[1] = (float)ce;
+        out3[2] = (float)kd;
+    }
+}
+
 template <int VEC, bool GRAD, bool EXT>
 __global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
     __shared__ double red[kKdThreads / 64][8];
@@ -452,53 +499,27 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) out8[k] = (k < (EXT ? 8 : 4)) ? acc[k % (EXT ? 8 : 4)] : 0.0;
     block_sum_store<8>(out8, red, a.main_partial + (long long)blockIdx.x * 8);
-}
 
-// One workgroup: fixed-order fp64 sum of the per-workgroup partials, then the scalar
-// epilogue of PixelKDLoss / CrossEntropyLoss / KDLiteLoss.
-__global__ __launch_bounds__(kKdFinalThreads) void kdlite_finalize_kernel(const double *__restrict__ partial,
-                                                                      int n_blocks, double *totals,
-                                                                      float *out3, float T, float alpha,
-                                                                      float bw, int conf) {
-    // thread t owns quantity t % 8 of workgroups t/8, t/8 + 32, ...: coalesced, then an LDS tree
-    __shared__ double red[kKdFinalThreads];
-    __shared__ double S[8];
-    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-    const int total = n_blocks * 8;
-    int i = threadIdx.x;
-    for (; i + 3 * kKdFinalThreads < total; i += 4 * kKdFinalThreads) {
-        v0 += partial[i];
-        v1 += partial[i + kKdFinalThreads];
-        v2 += partial[i + 2 * kKdFinalThreads];
-        v3 += partial[i + 3 * kKdFinalThreads];
-    }
-    for (; i < total; i += kKdFinalThreads) v0 += partial[i];
-    red[threadIdx.x] = (v0 + v1) + (v2 + v3);
+    // Hand the partial sums to whichever workgroup arrives last: drain the stores, one lane
+    // releases at agent scope and takes a ticket; the last arriver acquires and finalises.
+    __shared__ int last_flag;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int half = kKdFinalThreads / 2; half >= 8; half >>= 1) {
-        if ((int)threadIdx.x < half) red[threadIdx.x] += red[threadIdx.x + half];
-        __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == gridDim.x - 1);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        last_flag = last;
     }
-    if (threadIdx.x < 8) S[threadIdx.x] = red[threadIdx.x];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 0; k < 8; ++k) totals[k] = S[k];
-        const double T2 = (double)T * (double)T;
-        double kd = S[1] > 0.0 ? S[0] / S[1] : 0.0;
-        kd *= T2;
-        if (bw > 1.0f) {
-            const double kb = S[5] > 0.0 ? S[4] / S[5] : 0.0;
-            kd += ((double)bw - 1.0) * (kb * T2);
-        }
-        if (conf) {
-            const double kc = S[7] > 0.0 ? S[6] / S[7] : 0.0;
-            kd = 0.5 * kd + 0.5 * (kc * T2);
-        }
-        const double ce = S[2] / S[3];  // 0/0 -> NaN, as CrossEntropyLoss with nothing to average
-        out3[0] = (float)((double)alpha * ce + (1.0 - (double)alpha) * kd);
-        out3[1] = (float)ce;
-        out3[2] = (float)kd;
-    }
+    if (!last_flag) return;
+    kd_finalize(a.main_partial, (int)gridDim.x, a.totals, a.out3, a.T, a.alpha, a.bw, a.conf);
+    if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(256) void scale_inplace_kernel(float *x, int64_t n, const float *scale) {
@@ -590,6 +611,9 @@ extern "C" int spice_kdlite_forward(const float *student, const float *teacher, 
     a.pre_partial = reinterpret_cast<double *>(ws + kKdOffPre);
     a.main_partial = reinterpret_cast<double *>(ws + kKdOffMain);
     a.bad = reinterpret_cast<long long *>(ws + kKdOffBad);
+    a.ticket = reinterpret_cast<unsigned *>(ws + kKdOffTicket);
+    a.totals = reinterpret_cast<double *>(ws + kKdOffTotals);
+    a.out3 = out3;
     a.N = n;
     a.HW = hw;
     a.C = (int)c;
@@ -605,14 +629,8 @@ extern "C" int spice_kdlite_forward(const float *student, const float *teacher, 
     a.coef_kd = coef_kd;
     a.conf = params->confidence_weight != 0;
 
-    const int rc = vec4 ? kd_launch<4>(a, grad != nullptr, ext, (int)blocks, st)
-                        : kd_launch<1>(a, grad != nullptr, ext, (int)blocks, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(kdlite_finalize_kernel, dim3(1), dim3(kKdFinalThreads), 0, st, a.main_partial,
-                       (int)blocks, reinterpret_cast<double *>(ws + kKdOffTotals), out3, a.T, a.alpha,
-                       a.bw, a.conf);
-    SPICE_LAUNCH_CHECK();
-    return SPICE_OK;
+    return vec4 ? kd_launch<4>(a, grad != nullptr, ext, (int)blocks, st)
+                : kd_launch<1>(a, grad != nullptr, ext, (int)blocks, st);
 }
 
 extern "C" int spice_scale_inplace(float *x, int64_t n, const float *scale, void *stream) {

@@ -68,6 +68,8 @@ class SensitivitySweep:
                 self.candidates.append(Candidate(len(self.candidates), gi, float(r), np.sort(order[:n]),
                                                  1.0 - 0.5 * r * g.size / max(g.size, 1)))
         self.jobs: Dict[int, SliceJob] = {}
+        # when set to a list, evaluate() appends a (start, end) HIP event pair around each KD-Lite launch
+        self.kd_events: Optional[list] = None
 
     # -- host preparation for a set of candidates: plans + one shared index upload
     def prepare(self, indices: Sequence[int]) -> None:
@@ -104,7 +106,14 @@ class SensitivitySweep:
             logits = self.forward(images).contiguous()
             ops.argmax_confusion_update(conf_out, logits, labels, self.num_classes)
             if teacher_logits is not None and kd_out is not None:
-                out3, _, _ = ops.kdlite_forward(logits.float(), teacher_logits, labels, **self.kd)
+                student = logits.float()
+                if self.kd_events is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                out3, _, _ = ops.kdlite_forward(student, teacher_logits, labels, **self.kd)
+                if self.kd_events is not None:
+                    e1.record()
+                    self.kd_events.append((e0, e1))
                 kd_out.copy_(out3)
         finally:
             job.undo()

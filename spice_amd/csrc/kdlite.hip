@@ -13,10 +13,13 @@
 // order (thread -> wave butterfly -> workgroup -> one finalising workgroup): deterministic.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace spice {
 
 constexpr int kKdThreads = 256;
-constexpr int kKdMaxBlocks = 1024;
+constexpr int kKdMaxBlocks = 2048;  // capacity of the partial-sum tables in the workspace
+constexpr int kKdDefaultBlocks = 512;  // two workgroups per CU, each looping over its tiles
 constexpr float kNegFill = -1.0e30f;
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
@@ -332,13 +335,18 @@ __device__ __forceinline__ void kd_finalize(const double *partial, int n_blocks,
     double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
     const int total = n_blocks * 8;
     int i = threadIdx.x;
+    const unsigned long long *pu = reinterpret_cast<const unsigned long long *>(partial);
+    auto ld = [&](int j) {
+        return __longlong_as_double((long long)__hip_atomic_load(pu + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    };
     for (; i + 3 * kKdThreads < total; i += 4 * kKdThreads) {
-        v0 += partial[i];
-        v1 += partial[i + kKdThreads];
-        v2 += partial[i + 2 * kKdThreads];
-        v3 += partial[i + 3 * kKdThreads];
+        const double x0 = ld(i), x1 = ld(i + kKdThreads), x2 = ld(i + 2 * kKdThreads), x3 = ld(i + 3 * kKdThreads);
+        v0 += x0;
+        v1 += x1;
+        v2 += x2;
+        v3 += x3;
     }
-    for (; i < total; i += kKdThreads) v0 += partial[i];
+    for (; i < total; i += kKdThreads) v0 += ld(i);
     fin_red[threadIdx.x] = (v0 + v1) + (v2 + v3);
     __syncthreads();
     for (int half = kKdThreads / 2; half >= 8; half >>= 1) {
@@ -498,16 +506,29 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
     double out8[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) out8[k] = (k < (EXT ? 8 : 4)) ? acc[k % (EXT ? 8 : 4)] : 0.0;
-    block_sum_store<8>(out8, red, a.main_partial + (long long)blockIdx.x * 8);
-
-    // Hand the partial sums to whichever workgroup arrives last: drain the stores, one lane
-    // releases at agent scope and takes a ticket; the last arriver acquires and finalises.
+    // Hand the partial sums to whichever workgroup arrives last.  The eight sums are stored
+    // write-through (agent-scope atomic stores), so no release fence is needed; the storing wave
+    // drains them, one lane takes a ticket, and the last arriver acquires before reading.
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double v = wave_sum(out8[k]);
+            if (lane == 0) red[wave][k] = v;
+        }
+        __syncthreads();
+        if (tid < 8) {
+            double v = 0.0;
+            for (int wv = 0; wv < kKdThreads / 64; ++wv) v += red[wv][tid];
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.main_partial) + (long long)blockIdx.x * 8 + tid,
+                               (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     __shared__ int last_flag;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (t == gridDim.x - 1);
         if (last) {
@@ -537,6 +558,12 @@ __global__ __launch_bounds__(256) void scale_inplace_kernel(float *x, int64_t n,
         x4[i] = v;
     }
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) x[i] *= s;
+}
+
+static int kd_max_blocks() {
+    const char *e = getenv("SPICE_KD_MAX_BLOCKS");  // tuning knob (host side only)
+    const int v = e ? atoi(e) : 0;
+    return (v >= 1 && v <= kKdMaxBlocks) ? v : kKdDefaultBlocks;
 }
 
 template <int VEC>
@@ -599,7 +626,7 @@ extern "C" int spice_kdlite_forward(const float *student, const float *teacher, 
     if (tiles > INT32_MAX) return SPICE_ERR_UNSUPPORTED;
     int64_t blocks = tiles;
     if (blocks < 1) blocks = 1;
-    if (blocks > kKdMaxBlocks) blocks = kKdMaxBlocks;
+    if (blocks > kd_max_blocks()) blocks = kd_max_blocks();
 
     KdArgs a;
     a.s = student;

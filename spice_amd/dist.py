@@ -60,3 +60,15 @@ def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
 def barrier() -> None:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def sharded_tables(n_items: int, indices: Sequence[int], costs: Sequence[float], evaluate, tables: Sequence[torch.Tensor]) -> None:
+    """Every rank runs `evaluate(i)` for its cost-balanced share of `indices` (each call fills row
+    i of the zero-initialised `tables`), then the tables are summed over ranks: afterwards every
+    rank holds every row.  No communication happens before the final all-reduce."""
+    rank, n_ranks = world()
+    parts = partition_by_cost(list(costs), n_ranks)
+    for k in parts[rank]:
+        evaluate(indices[k])
+    for t in tables:
+        all_reduce_sum_(t)

@@ -22,8 +22,15 @@ from .. import ops
 logger = logging.getLogger(__name__)
 
 
+def _hip_row_reduce(weights, grads, out, accumulate):
+    ops.channel_importance(weights, nat.IMP_TAYLOR, grads=grads, out=out, accumulate=accumulate)
+
+
 def compute_taylor_scores(model: nn.Module, dataloader, device: str, max_batches: int = 100,
-                          shard: bool = False) -> Dict[nn.Module, torch.Tensor]:
+                          shard: bool = False, _row_reduce=_hip_row_reduce) -> Dict[nn.Module, torch.Tensor]:
+    """`_row_reduce(weights, grads, out, accumulate)` is the per-channel reduction; the default and
+    only product implementation is the HIP kernel (tests substitute a checker to exercise the
+    batch sharding and the all-reduce on machines without a GPU)."""
     was_training = model.training
     model.eval()  # also puts every BatchNorm in eval mode
     convs = [m for m in model.modules() if isinstance(m, nn.Conv2d)]
@@ -61,14 +68,16 @@ def compute_taylor_scores(model: nn.Module, dataloader, device: str, max_batches
         live = [(m, o) for m, o in zip(convs, offsets) if m.weight.grad is not None]
         if live:
             if len(live) == len(convs):
-                ops.channel_importance([m.weight.detach() for m in convs], nat.IMP_TAYLOR,
-                                       grads=[m.weight.grad for m in convs], out=flat[:total],
-                                       accumulate=True)
+                _row_reduce([m.weight.detach() for m in convs], [m.weight.grad for m in convs],
+                            flat[:total], True)
             else:  # some convolutions took no part in the loss: reduce the others only
-                part, offs = ops.channel_importance([m.weight.detach() for m, _ in live], nat.IMP_TAYLOR,
-                                                    grads=[m.weight.grad for m, _ in live])
-                for (m, o), po in zip(live, offs):
+                n_live = sum(m.out_channels for m, _ in live)
+                part = torch.zeros(n_live, dtype=torch.float32, device=device)
+                _row_reduce([m.weight.detach() for m, _ in live], [m.weight.grad for m, _ in live], part, False)
+                po = 0
+                for m, o in live:
                     flat[o: o + m.out_channels] += part[po: po + m.out_channels]
+                    po += m.out_channels
         seen += 1
 
     if world > 1:

@@ -126,18 +126,16 @@ class SensitivitySweep:
         n = len(self.candidates)
         indices = list(range(n)) if indices is None else list(indices)
         rank, world = sdist.world()
-        parts = sdist.partition_by_cost([self.candidates[i].cost for i in indices], world)
-        mine = [indices[k] for k in parts[rank]]
-        self.prepare(mine)
+        costs = [self.candidates[i].cost for i in indices]
+        parts = sdist.partition_by_cost(costs, world)
+        self.prepare([indices[k] for k in parts[rank]])
         c = self.num_classes
         table = torch.zeros(n, c, c, dtype=torch.int64, device=self.device)
         kd = torch.zeros(n, 3, dtype=torch.float32, device=self.device)
         teacher = self.forward(images).float().contiguous() if with_kd else None
-        for i in mine:
-            self.evaluate(i, images, labels, teacher, table[i], kd[i] if with_kd else None)
-        sdist.all_reduce_sum_(table)
-        if with_kd:
-            sdist.all_reduce_sum_(kd)
+        sdist.sharded_tables(n, indices, costs,
+                             lambda i: self.evaluate(i, images, labels, teacher, table[i], kd[i] if with_kd else None),
+                             [table, kd] if with_kd else [table])
         return {"confusion": table, "kd": kd, "miou": miou_from_confusion(table)}
 
 

@@ -44,8 +44,8 @@ static inline int argmax_blocks(int64_t n_threads_needed) {
 }
 
 static inline int conf_blocks(int64_t n_pixels) {
-    // one workgroup per ~16K pixels, at most kConfMaxBlocks
-    int64_t b = ceil_div(n_pixels, (int64_t)kConfThreads * 32);
+    // one workgroup per ~8K pixels (one per CU for an 8x512x512 batch), at most kConfMaxBlocks
+    int64_t b = ceil_div(n_pixels, (int64_t)kConfThreads * 16);
     if (b < 1) b = 1;
     if (b > kConfMaxBlocks) b = kConfMaxBlocks;
     return (int)b;

@@ -26,27 +26,42 @@ __global__ __launch_bounds__(kGatherThreads) void gather_kernel(
     const long long *idx_in = it.idx_in_off >= 0 ? idx_base + it.idx_in_off : nullptr;
     const bool vec = bases_vec_ok && (it.flags & 1);
 
+    if (idx_in == nullptr && vec) {
+        // Whole rows, 16 bytes per lane.  A lane group moves four rows at a time: the four row ids
+        // are fetched first, then the four loads of each column step are issued back to back, so
+        // the id lookup and the row data of different rows overlap instead of chaining.
+        const int n4 = row_len >> 2;
+        for (int r = sub; r < it.n_rows; r += 4 * groups) {
+            const uint4 *s4[4];
+            uint4 *d4[4];
+            bool ok[4];
+            long long so[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = r + i * groups;
+                ok[i] = row < it.n_rows;
+                const int rr = ok[i] ? row : r;  // surplus slots re-read row r and store nothing
+                so[i] = idx_out ? idx_out[rr] : (long long)(it.row0 + rr);
+                d4[i] = reinterpret_cast<uint4 *>(dst + (int64_t)rr * row_len);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s4[i] = reinterpret_cast<const uint4 *>(src + so[i] * src_row_stride);
+            for (int j = lane; j < n4; j += L) {
+                const uint4 v0 = s4[0][j], v1 = s4[1][j], v2 = s4[2][j], v3 = s4[3][j];
+                d4[0][j] = v0;
+                if (ok[1]) d4[1][j] = v1;
+                if (ok[2]) d4[2][j] = v2;
+                if (ok[3]) d4[3][j] = v3;
+            }
+        }
+        return;
+    }
     for (int r = sub; r < it.n_rows; r += groups) {
         const int64_t so = idx_out ? (int64_t)idx_out[r] : (int64_t)(it.row0 + r);
         const unsigned *srow = src + so * src_row_stride;
         unsigned *drow = dst + (int64_t)r * row_len;
         if (idx_in == nullptr) {
-            if (vec) {
-                const uint4 *s4 = reinterpret_cast<const uint4 *>(srow);
-                uint4 *d4 = reinterpret_cast<uint4 *>(drow);
-                const int n4 = row_len >> 2;
-                int j = lane;
-                for (; j + 3 * L < n4; j += 4 * L) {
-                    const uint4 a = s4[j], b = s4[j + L], c = s4[j + 2 * L], d = s4[j + 3 * L];
-                    d4[j] = a;
-                    d4[j + L] = b;
-                    d4[j + 2 * L] = c;
-                    d4[j + 3 * L] = d;
-                }
-                for (; j < n4; j += L) d4[j] = s4[j];
-            } else {
-                for (int j = lane; j < row_len; j += L) drow[j] = srow[j];
-            }
+            for (int j = lane; j < row_len; j += L) drow[j] = srow[j];
         } else if (it.inner == 1) {
             for (int j = lane; j < row_len; j += L) drow[j] = srow[idx_in[j]];
         } else {

@@ -64,7 +64,9 @@ def taylor_and_quotas(model, images, labels, dev):
     return scores, quotas, t1 - t0
 
 
-def event_ms(fn, iters, warmup=3):
+def event_ms(fn, iters, warmup=3, batch=8):
+    """Median time per launch over `iters` batches of `batch` back-to-back launches (the GPU stays
+    busy inside a batch, so host launch latency is not part of the figure)."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -72,11 +74,22 @@ def event_ms(fn, iters, warmup=3):
     for _ in range(iters):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        fn()
+        for _ in range(batch):
+            fn()
         b.record()
         b.synchronize()
-        times.append(a.elapsed_time(b))
+        times.append(a.elapsed_time(b) / batch)
     return float(np.median(times))
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (None if absent)."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["kernels"][kernel_key]["hbm_bytes_corrected"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def kernel_table(dev):
@@ -138,7 +151,7 @@ def kernel_table(dev):
     row("kdlite forward (T=4, alpha=0.7)",
         event_ms(lambda: ops.kdlite_forward(*cyc(sets), temperature=4.0, alpha=0.7), 20), P * (2 * CLASSES * 4 + 8))
     row("kdlite forward+grad (label pre-pass + fused pass)",
-        event_ms(lambda: ops.kdlite_forward(*cyc(sets), temperature=4.0, alpha=0.7, want_grad=True), 10),
+        event_ms(lambda: ops.kdlite_forward(*cyc(sets), temperature=4.0, alpha=0.7, want_grad=True), 10, batch=4),
         P * (3 * CLASSES * 4 + 8))
     lg16 = [s[0].half() for s in sets] + [sets[0][1].half()]
     conf = torch.zeros(CLASSES, CLASSES, dtype=torch.int64, device=dev)
@@ -156,7 +169,7 @@ def kernel_table(dev):
     p5 = torch.randint(0, 19, (P5,), device=dev)
     conf5 = torch.zeros(19, 19, dtype=torch.int64, device=dev)
     row("confusion [32,1024,2048] int64, 19 classes",
-        event_ms(lambda: ops.confusion_update(conf5, p5, t5, 19), 10), P5 * 16)
+        event_ms(lambda: ops.confusion_update(conf5, p5, t5, 19), 10, batch=4), P5 * 16)
     return out
 
 
@@ -275,7 +288,8 @@ def main():
                    "kd": {"T": 4.0, "alpha": 0.7}, "parallelism": f"candidates sharded over {world} rank(s)"},
         "roofline": {"bound": "hbm", "kernel": "spice::kdlite_main_kernel<4,false,false> (one launch per "
                      "spice_kdlite_forward call)", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS,
-                     "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4),
+                     "traffic": pmc_traffic("spice::kdlite_main_kernel<4, false, false>"),
                      "algorithmic_bytes_per_launch": kd_bytes, "avg_launch_us": round(1e3 * kd_ms, 2),
                      "launches_timed": len(kd_events)},
         "setup": {"taylor_calibration_s": round(taylor_s, 3), "taylor_batches": 2,

@@ -265,8 +265,7 @@ def main():
     kd_events = sweep.kd_events
     sweep.kd_events = None
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    sdist.all_reduce_max_(t)
     elapsed = float(t.item())
 
     kd_ms = float(np.mean([a.elapsed_time(b) for a, b in kd_events])) if kd_events else float("nan")

@@ -1,9 +1,10 @@
-"""Data handling for pruning runs.
+"""Data handling for pruning runs (pruning/dataset.py:13-55).
 
 The reference reads a Pascal-VOC-style insect dataset that does not ship with it
-(data/data.py:97-244, pruning/dataset.py:12-55; data/ is git-ignored).  When `data_root` holds no
-`train/` directory the handler serves a deterministic synthetic dataset of the configured
-geometry instead (the reference's own precedent: quantization/quant_utils.py:13-19).
+(data/data.py:97-244; data/ is git-ignored).  When `data_root` holds no `train/` directory the
+handler serves a deterministic synthetic dataset of the configured geometry instead (the
+reference's own precedent: quantization/quant_utils.py:13-19).  With several ranks the training
+split is sharded by a DistributedSampler; validation and test splits are sharded by index stride.
 """
 from __future__ import annotations
 
@@ -12,8 +13,10 @@ from typing import Tuple
 
 import numpy as np
 import torch
-from torch.utils.data import DataLoader, Dataset
+from torch.utils.data import DataLoader, Dataset, Subset
+from torch.utils.data.distributed import DistributedSampler
 
+from .. import dist as sdist
 from .. import synth
 
 
@@ -39,7 +42,7 @@ class SyntheticSegmentationDataset(Dataset):
 
 
 class PruningDataHandler:
-    def __init__(self, data_root: str = "data", batch_size: int = 8, num_workers: int = 4,
+    def __init__(self, data_root: str = "data", batch_size: int = 4, num_workers: int = 2,
                  seed: int = 42, num_classes: int = 5, input_size: Tuple[int, int] = (576, 576),
                  synthetic_length: int = 32):
         self.data_root, self.batch_size, self.num_workers, self.seed = data_root, batch_size, num_workers, seed
@@ -54,16 +57,29 @@ class PruningDataHandler:
         return SyntheticSegmentationDataset(self.synthetic_length, self.num_classes, self.input_size,
                                             self.seed + offset, ignore_share)
 
-    def _loader(self, split: str, shuffle: bool, ignore_share: float = 0.0) -> DataLoader:
+    def _loader(self, split: str, shuffle: bool, ignore_share: float = 0.0, distribute: bool = True) -> DataLoader:
+        data = self._dataset(split, ignore_share)
+        rank, world = sdist.world() if distribute else (0, 1)
         g = torch.Generator()
         g.manual_seed(self.seed)
-        return DataLoader(self._dataset(split, ignore_share), batch_size=self.batch_size, shuffle=shuffle,
-                          num_workers=0, generator=g, drop_last=False)
+        if world > 1 and shuffle:
+            sampler = DistributedSampler(data, num_replicas=world, rank=rank, shuffle=True, seed=self.seed)
+            return DataLoader(data, batch_size=self.batch_size, sampler=sampler, num_workers=0, drop_last=False)
+        if world > 1:
+            data = Subset(data, list(range(rank, len(data), world)))
+        return DataLoader(data, batch_size=self.batch_size, shuffle=shuffle, num_workers=0, generator=g,
+                          drop_last=False)
 
-    def get_loaders(self):
+    def get_dataloaders(self) -> Tuple[DataLoader, DataLoader, DataLoader]:
+        """(train, valid, test), as data/data.py:170-244 returns them."""
         return (self._loader("train", True, 0.05), self._loader("valid", False, 0.05),
                 self._loader("test", False, 0.05))
 
+    def get_train_val_loaders(self) -> Tuple[DataLoader, DataLoader]:
+        train, val, _ = self.get_dataloaders()
+        return train, val
+
     def get_calibration_dataloader(self) -> DataLoader:
-        # the Taylor pass uses cross-entropy without ignore_index: labels must be in [0, C)
-        return self._loader("train", True, 0.0)
+        # the Taylor pass uses cross-entropy without ignore_index: labels must be in [0, C).
+        # Every rank iterates the same seeded order; the Taylor pass itself takes batches round-robin.
+        return self._loader("train", True, 0.0, distribute=False)

@@ -1,7 +1,6 @@
 """Quota allocation and the end-to-end pruning run (pruning/pruner.py:26-812)."""
 from __future__ import annotations
 
-import copy
 import datetime
 import logging
 from abc import ABC, abstractmethod
@@ -11,15 +10,15 @@ from typing import Any, Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
+from .. import dist as sdist
 from .. import engine
 from .config import PruningConfig
-from .dataset import PruningDataHandler
 from .models import ModelFactory
 from .pruning_core import PruningOrchestrator, compute_model_statistics
 from .sensitivity import TaylorWeightImportance
 from .tracking import WandBTracker
 from .trainer import PruningMetrics, PruningTrainer
-from .utils import calculate_model_size_mb, count_model_parameters, set_random_seeds
+from .utils import set_random_seeds
 
 logger = logging.getLogger(__name__)
 
@@ -145,127 +144,283 @@ def create_hybrid_pruner(model, config, taylor_importance, example_inputs, ignor
 
 class TrainingStrategy(ABC):
     @abstractmethod
-    def train_model(self, trainer, model, loaders, epochs, teacher=None) -> Dict:
+    def train_model(self, trainer: "PruningTrainer", model: nn.Module, epochs: int, step_info: str,
+                    teacher_model: Optional[nn.Module] = None) -> nn.Module:
         ...
 
 
 class StandardTrainingStrategy(TrainingStrategy):
-    def train_model(self, trainer, model, loaders, epochs, teacher=None):
-        return trainer.fine_tune(model, loaders[0], loaders[1], epochs, teacher=None)
+    def train_model(self, trainer, model, epochs, step_info, teacher_model=None):
+        return trainer.fine_tune(model, epochs, step_info, teacher_model=None)
 
 
 class KDTrainingStrategy(TrainingStrategy):
-    def train_model(self, trainer, model, loaders, epochs, teacher=None):
-        return trainer.fine_tune(model, loaders[0], loaders[1], epochs, teacher=teacher)
+    def train_model(self, trainer, model, epochs, step_info, teacher_model=None):
+        return trainer.fine_tune(model, epochs, step_info, teacher_model=teacher_model)
 
 
-class ModelManager:
-    """Model loading and the output directory layout
-    {model}_{strategy}_{ratio:.2f}[_kd|_kd_refine] (pruning/pruner.py:415-475)."""
+class RefinedKDTrainingStrategy(TrainingStrategy):
+    """Standard fine-tuning for `epochs`, then kd_refine_epochs of distillation
+    (pruning/pruner.py:371-398)."""
 
     def __init__(self, config: PruningConfig):
         self.config = config
+        self.standard_strategy = StandardTrainingStrategy()
+        self.kd_strategy = KDTrainingStrategy()
 
-    def run_directory(self) -> Path:
+    def train_model(self, trainer, model, epochs, step_info, teacher_model=None):
+        logger.info("Stage 1: Standard fine-tuning")
+        model = self.standard_strategy.train_model(trainer, model, epochs, f"{step_info} - Standard")
+        logger.info("Stage 2: KD refinement")
+        return self.kd_strategy.train_model(trainer, model, getattr(self.config, "kd_refine_epochs", epochs),
+                                            f"{step_info} - KD Refine", teacher_model)
+
+
+class TrainingStrategyFactory:
+    @staticmethod
+    def create_strategy(config: PruningConfig) -> TrainingStrategy:
+        if not config.enable_kd_lite:
+            return StandardTrainingStrategy()
+        if getattr(config, "kd_mode", "") == "refine":
+            return RefinedKDTrainingStrategy(config)
+        return KDTrainingStrategy()
+
+
+class ModelManager:
+    """Model loading and the output directory layout (pruning/pruner.py:415-475):
+    <output_dir>/[<YYYYmmdd_HHMMSS>_]<model>_<strategy>_<ratio:.2f>[_kd|_kd_refine]/
+        final_model.pth  model_info.txt  metrics.json  [sensitivity_report.json | hybrid_pruning_report.json]
+        intermediate/<model>_step_<i>_of_<n>.pth"""
+
+    def __init__(self, config: PruningConfig):
+        self.config = config
+        self.model_factory = ModelFactory()
+        self.pruning_dir = self._create_output_directory()
+        self.intermediate_dir = self.pruning_dir / "intermediate"
+        self.intermediate_dir.mkdir(parents=True, exist_ok=True)
+
+    def _create_output_directory(self) -> Path:
         c = self.config
         name = f"{c.model_name}_{c.pruning_strategy}_{c.pruning_ratio:.2f}"
         if c.enable_kd_lite:
-            name += "_kd_refine" if c.kd_mode == "refine" else "_kd"
+            name += "_kd_refine" if getattr(c, "kd_mode", "") == "refine" else "_kd"
         if c.use_timestamp:
-            name = datetime.datetime.now().strftime("%Y%m%d_%H%M%S_") + name
+            name = datetime.datetime.now().strftime("%Y%m%d_%H%M%S") + "_" + name
         d = Path(c.output_dir) / name
-        (d / "intermediate").mkdir(parents=True, exist_ok=True)
+        d.mkdir(parents=True, exist_ok=True)
         return d
 
-    def load(self) -> nn.Module:
-        return ModelFactory.load_pretrained_model(self.config)
+    def load_model(self) -> nn.Module:
+        set_random_seeds(self.config.seed)
+        model = self.model_factory.load_pretrained_model(self.config)
+        model.to(self.config.device)
+        return model
 
-    def save_intermediate_model(self, model, run_dir: Path, step: int, total: int) -> Path:
-        path = run_dir / "intermediate" / f"{self.config.model_name}_step_{step}_of_{total}.pth"
+    def save_intermediate_model(self, model: nn.Module, step: int, total_steps: int) -> None:
+        if sdist.world()[0] != 0:  # one writer per run
+            return
+        path = self.intermediate_dir / f"{self.config.model_name}_step_{step}_of_{total_steps}.pth"
+        model.zero_grad()
         torch.save(model, path)
+        logger.debug(f"Saved intermediate pruned model: {path}")
+
+    def save_final_model(self, model: nn.Module) -> Path:
+        model.cpu()  # the saved module loads on hosts without a GPU (pruning/pruner.py:467)
+        path = self.pruning_dir / "final_model.pth"
+        self.model_factory.save_model(model, str(path), self.config)
+        return path
+
+    def save_metrics(self, metrics: "PruningMetrics") -> Path:
+        path = self.pruning_dir / "metrics.json"
+        metrics.save_history(str(path))
         return path
 
 
 class PruningStepExecutor:
-    def __init__(self, config, trainer, model_manager, training_strategy, tracker):
-        self.config, self.trainer, self.models = config, trainer, model_manager
-        self.training_strategy, self.tracker = training_strategy, tracker
+    def __init__(self, config: PruningConfig, model_manager: ModelManager):
+        self.config = config
+        self.model_manager = model_manager
+        self.training_strategy = TrainingStrategyFactory.create_strategy(config)
 
-    def execute_pruning_step(self, pruner, model, example_inputs, loaders, step, total, run_dir, teacher):
+    def execute_pruning_step(self, step: int, pruner, model: nn.Module, trainer: "PruningTrainer",
+                             metrics: "PruningMetrics", teacher_model: Optional[nn.Module] = None) -> nn.Module:
+        """`step` counts from 0.  One pruner.step() (importance -> selection -> physical slicing),
+        statistics, fine-tuning, intermediate checkpoint, one metrics row.  The row's loss fields
+        are written as 0.0, as the reference writes them (pruning/pruner.py:513-519); the real
+        losses are on the trainer (last_train_loss / last_val_loss) and go to the tracker."""
         pruner.step()
-        stats = compute_model_statistics(model, example_inputs)
-        logger.info(f"Step {step}/{total}: {stats['params_million']:.2f}M params, {stats['macs_million']:.1f}M MACs")
-        train = self.training_strategy.train_model(self.trainer, model, loaders, self.config.fine_tune_epochs,
-                                                   teacher=teacher)
-        self.models.save_intermediate_model(model, run_dir, step, total)
-        return {**stats, **train}
+        stats = compute_model_statistics(model, self._generate_example_inputs(step))
+        if step == 0:
+            self.initial_params = stats["params"]
+        stats["compression_ratio"] = stats["params"] / self.initial_params
+        model = self.training_strategy.train_model(trainer, model, self.config.fine_tune_epochs,
+                                                   f"Step {step + 1}/{self.config.iterative_steps}", teacher_model)
+        self.model_manager.save_intermediate_model(model, step + 1, self.config.iterative_steps)
+        metrics.add_step(step=step + 1, train_loss=0.0, val_loss=0.0, params=stats["params"], macs=stats["macs"])
+        tracker = getattr(trainer, "wandb_tracker", None)
+        if tracker:
+            tracker.log_pruning_step(step=step + 1, model_stats=stats,
+                                     train_loss=getattr(trainer, "last_train_loss", 0.0),
+                                     val_loss=getattr(trainer, "last_val_loss", 0.0))
+        return model
 
-    def execute_final_training(self, model, loaders, teacher):
-        return self.training_strategy.train_model(self.trainer, model, loaders,
-                                                  self.config.final_fine_tune_epochs, teacher=teacher)
+    def execute_final_training(self, model: nn.Module, trainer: "PruningTrainer",
+                               teacher_model: Optional[nn.Module] = None) -> nn.Module:
+        logger.info(f"\n--- Final Fine-tuning ({self.config.final_fine_tune_epochs} epochs) ---")
+        return self.training_strategy.train_model(trainer, model, self.config.final_fine_tune_epochs, "Final",
+                                                  teacher_model)
+
+    def _generate_example_inputs(self, step: int) -> torch.Tensor:
+        torch.manual_seed(self.config.seed + step)
+        return torch.randn(*self.config.example_input_size).to(self.config.device)
 
 
 class StructuredPruner:
+    """The whole run (pruning/pruner.py:552-806): load, analyse, prune in steps with fine-tuning,
+    final fine-tuning, artefacts.  Under several ranks every rank prunes its replica identically
+    (the analysis is all-reduced, selection is deterministic) and rank 0 writes the files."""
+
     def __init__(self, config: PruningConfig):
         self.config = config
         set_random_seeds(config.seed)
-        self.tracker = WandBTracker(config, enabled=config.use_wandb)
         self.model_manager = ModelManager(config)
-        self.trainer = PruningTrainer(config, self.tracker)
-        self.orchestrator = PruningOrchestrator(config)
-        self.orchestrator.set_wandb_tracker(self.tracker)
+        self.trainer = PruningTrainer(config)
         self.metrics = PruningMetrics()
+        self.orchestrator = PruningOrchestrator(config)
+        self.step_executor = PruningStepExecutor(config, self.model_manager)
+        self.wandb_tracker = WandBTracker(config=config, project=config.wandb_project, entity=config.wandb_entity,
+                                          name=config.wandb_run_name, tags=config.wandb_tags,
+                                          enabled=config.use_wandb)
+        self.trainer.set_wandb_tracker(self.wandb_tracker)
+        self.orchestrator.set_wandb_tracker(self.wandb_tracker)
 
     def prune(self) -> Dict[str, Any]:
+        self._log_pruning_info()
         try:
-            return self._run()
+            if torch.device(self.config.device).type != "cuda":
+                raise RuntimeError(f"device '{self.config.device}': this implementation runs on HIP devices only")
+            model, teacher_model, initial_info = self._initialize_models()
+            pruner, additional_info = self._setup_pruning(model)
+            self.orchestrator.save_reports(self.model_manager.pruning_dir, additional_info)
+            model = self._execute_progressive_pruning(model, pruner, teacher_model)
+            model = self.step_executor.execute_final_training(model, self.trainer, teacher_model)
+            return self._finalize_pruning(model, initial_info)
         except Exception as e:
             logger.error(f"Pruning failed: {e}")
             raise
         finally:
             self.trainer.cleanup()
 
-    def _run(self) -> Dict[str, Any]:
+    def _log_pruning_info(self) -> None:
         c = self.config
-        if torch.device(c.device).type != "cuda":
-            raise RuntimeError(f"device '{c.device}': this implementation runs on HIP devices only")
-        model = self.model_manager.load()
-        teacher = copy.deepcopy(model).eval() if c.enable_kd_lite else None
-        torch.manual_seed(c.seed)
-        example_inputs = torch.randn(*c.example_input_size).to(c.device)
-        initial = compute_model_statistics(model, example_inputs)
-        initial_size = calculate_model_size_mb(model)
-        ignored = ModelFactory.get_ignored_layers(model)
+        logger.info(f"Starting structured pruning of {c.model_name}")
+        logger.info(f"Strategy: {c.pruning_strategy}, Ratio: {c.pruning_ratio}, Steps: {c.iterative_steps}")
+        if c.enable_kd_lite:
+            logger.info(f"KD-Lite enabled: Temperature={c.kd_temperature}, Alpha={c.kd_alpha}, "
+                        f"Data ratio={c.kd_data_ratio}")
+
+    def _initialize_models(self) -> Tuple[nn.Module, Optional[nn.Module], Dict]:
+        model = self.model_manager.load_model()
+        teacher_model = None
+        if self.config.enable_kd_lite:
+            logger.info("Saving original model as teacher for KD-Lite")
+            teacher_model = self.model_manager.load_model()
+            teacher_model.eval()
+            for p in teacher_model.parameters():
+                p.requires_grad = False
+        initial_info = self.model_manager.model_factory.get_model_info(model)
+        example_inputs = torch.randn(*self.config.example_input_size).to(self.config.device)
+        stats = compute_model_statistics(model, example_inputs)
+        initial_info["macs"], initial_info["macs_million"] = stats["macs"], stats["macs_million"]
+        logger.info(f"Initial model: {initial_info['total_params']:,} parameters, "
+                    f"{initial_info['model_size_mb']:.2f} MB, {initial_info['macs_million']:.2f}M MACs")
+        self.wandb_tracker.log_initial_model_info(initial_info)
+        return model, teacher_model, initial_info
+
+    def _setup_pruning(self, model: nn.Module):
+        ignored = self.model_manager.model_factory.get_ignored_layers(model, self.config)
+        torch.manual_seed(self.config.seed)
+        example_inputs = torch.randn(*self.config.example_input_size).to(self.config.device)
+        self.wandb_tracker.log_model_graph(model, example_inputs)
         pruner, info = self.orchestrator.setup_importance_and_pruner(model, example_inputs, ignored)
-        run_dir = self.model_manager.run_directory()
-        self.orchestrator.save_reports(run_dir, info)
-        handler = PruningDataHandler(c.data_root, c.batch_size, c.num_workers, c.seed, c.num_classes, c.input_size)
-        loaders = handler.get_loaders()
-        strategy = KDTrainingStrategy() if c.enable_kd_lite else StandardTrainingStrategy()
-        executor = PruningStepExecutor(c, self.trainer, self.model_manager, strategy, self.tracker)
-        for step in range(1, c.iterative_steps + 1):
-            row = executor.execute_pruning_step(pruner, model, example_inputs, loaders, step,
-                                                c.iterative_steps, run_dir, teacher)
-            self.metrics.add_step(step, **row)
-        final_train = executor.execute_final_training(model, loaders, teacher)
-        final = compute_model_statistics(model, example_inputs)
-        out_path = run_dir / "final_model.pth"
-        ModelFactory.save_model(model, out_path, {"strategy": c.pruning_strategy, "ratio": c.pruning_ratio})
-        self.metrics.save(run_dir / "metrics.json")
-        final_size = calculate_model_size_mb(model)
-        return {
-            "model_name": c.model_name, "pruning_strategy": c.pruning_strategy,
-            "pruning_ratio": c.pruning_ratio, "kd_lite_enabled": c.enable_kd_lite,
-            "kd_temperature": c.kd_temperature, "kd_alpha": c.kd_alpha,
-            "initial_params": initial["params"], "final_params": final["params"],
-            "params_reduction": 1 - final["params"] / max(initial["params"], 1),
-            "initial_macs": initial["macs"], "final_macs": final["macs"],
-            "initial_size_mb": initial_size, "final_size_mb": final_size,
-            "size_reduction": 1 - final_size / max(initial_size, 1e-12),
-            "output_path": str(out_path), "final_training": final_train,
-            "steps": self.metrics.history,
+        if "sensitivity_report" in info:
+            self.wandb_tracker.log_sensitivity_analysis(info["sensitivity_report"])
+        elif "hybrid_report" in info:
+            quota = info["hybrid_report"].get("quota_allocation")
+            self.wandb_tracker.log_sensitivity_analysis(info["hybrid_report"], layer_quotas=quota)
+            if quota and quota.get("layer_details"):
+                self.wandb_tracker.log_layer_pruning_details(quota["layer_details"])
+        return pruner, info
+
+    def _execute_progressive_pruning(self, model: nn.Module, pruner, teacher_model: Optional[nn.Module]) -> nn.Module:
+        logger.info("Starting progressive pruning...")
+        for step in range(self.config.iterative_steps):
+            model = self.step_executor.execute_pruning_step(step, pruner, model, self.trainer, self.metrics,
+                                                            teacher_model)
+            row = self.metrics.history[-1]
+            logger.info(f"Pruning Step {step + 1}/{self.config.iterative_steps}: "
+                        f"Params {row['params_million']:.2f}M, MACs {row['macs_million']:.2f}M")
+        return model
+
+    def _finalize_pruning(self, model: nn.Module, initial_info: Dict) -> Dict[str, Any]:
+        model.to(self.config.device)
+        example_inputs = torch.randn(*self.config.example_input_size).to(self.config.device)
+        final_stats = compute_model_statistics(model, example_inputs)
+        rank, _ = sdist.world()
+        if rank == 0:
+            final_path = self.model_manager.save_final_model(model)
+            metrics_path = self.model_manager.save_metrics(self.metrics)
+        else:
+            final_path = self.model_manager.pruning_dir / "final_model.pth"
+            metrics_path = self.model_manager.pruning_dir / "metrics.json"
+        sdist.barrier()
+        final_info = self.model_manager.model_factory.get_model_info(model)
+        final_info["macs"], final_info["macs_million"] = final_stats["macs"], final_stats["macs_million"]
+        results = self._build_results_dict(initial_info, final_info, final_path, metrics_path)
+        self._log_final_results(results)
+        self.wandb_tracker.log_final_results(results)
+        self.wandb_tracker.create_comparison_chart(
+            {"params": initial_info["total_params"], "macs": initial_info.get("macs", 0)},
+            {"params": final_info["total_params"], "macs": final_info.get("macs", 0)})
+        if self.config.wandb_save_model:
+            self.wandb_tracker.save_model_checkpoint(str(final_path),
+                                                     aliases=["latest", f"ratio_{self.config.pruning_ratio}"])
+        self.wandb_tracker.finish()
+        return results
+
+    def _build_results_dict(self, initial_info: Dict, final_info: Dict, final_path: Path,
+                            metrics_path: Path) -> Dict[str, Any]:
+        c = self.config
+
+        def drop(key):
+            before = initial_info.get(key, 0)
+            return (before - final_info.get(key, 0)) / before if before > 0 else 0
+
+        results = {
+            "model_name": c.model_name, "pruning_strategy": c.pruning_strategy, "pruning_ratio": c.pruning_ratio,
+            "initial_params": initial_info["total_params"], "final_params": final_info["total_params"],
+            "params_reduction": drop("total_params"),
+            "initial_size_mb": initial_info["model_size_mb"], "final_size_mb": final_info["model_size_mb"],
+            "size_reduction": drop("model_size_mb"),
+            "initial_macs": initial_info.get("macs", 0), "final_macs": final_info.get("macs", 0),
+            "macs_reduction": drop("macs"),
+            "output_path": str(final_path), "metrics_path": str(metrics_path),
+            "pruning_dir": str(self.model_manager.pruning_dir), "kd_lite_enabled": c.enable_kd_lite,
         }
+        if c.enable_kd_lite:
+            results.update({"kd_temperature": c.kd_temperature, "kd_alpha": c.kd_alpha,
+                            "kd_data_ratio": c.kd_data_ratio})
+        return results
+
+    def _log_final_results(self, results: Dict[str, Any]) -> None:
+        logger.info("\n--- Pruning Complete ---")
+        logger.info(f"Parameters: {results['initial_params']:,} → {results['final_params']:,} "
+                    f"({results['params_reduction']:.2%} reduction)")
+        logger.info(f"Model size: {results['initial_size_mb']:.2f} MB → {results['final_size_mb']:.2f} MB "
+                    f"({results['size_reduction']:.2%} reduction)")
+        logger.info(f"Saved to: {results['output_path']}")
 
 
 def prune_model(config: PruningConfig) -> Dict[str, Any]:
+    set_random_seeds(config.seed)
     return StructuredPruner(config).prune()

@@ -9,6 +9,7 @@ from typing import Any, Dict, List, Tuple
 import torch
 import torch.nn as nn
 
+from .. import dist as sdist
 from .. import engine
 from .config import PruningConfig
 from .dataset import PruningDataHandler
@@ -69,6 +70,8 @@ class PruningOrchestrator:
             ignored_layers=ignored_layers, global_pruning=True)
 
     def save_reports(self, pruning_dir: Path, additional_info: Dict) -> None:
+        if sdist.world()[0] != 0:  # one writer per run
+            return
         for key, fname in (("sensitivity_report", "sensitivity_report.json"),
                            ("hybrid_report", "hybrid_pruning_report.json")):
             if key in additional_info:

@@ -37,7 +37,8 @@ class TaylorWeightImportance(Importance):
         logger.info(f"Computed sensitivity for {len(self.sensitivity_scores)} layers")
 
     def _compute_sensitivity(self, model, dataloader, device, max_batches) -> Dict[nn.Module, torch.Tensor]:
-        return compute_taylor_scores(model, dataloader, device, max_batches)
+        # with several ranks: calibration batches round-robin, one all-reduce of the flat score buffer
+        return compute_taylor_scores(model, dataloader, device, max_batches, shard=True)
 
     def __call__(self, group) -> torch.Tensor:
         members = _members(group) if group else []

@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _native as nat
+from .. import dist as sdist
 from .. import ops
 
 logger = logging.getLogger(__name__)
@@ -82,8 +83,8 @@ def compute_taylor_scores(model: nn.Module, dataloader, device: str, max_batches
 
     if world > 1:
         counter = torch.tensor([float(seen)], device=device)
-        torch.distributed.all_reduce(flat)
-        torch.distributed.all_reduce(counter)
+        sdist.all_reduce_sum_(flat)
+        sdist.all_reduce_sum_(counter)
         seen = int(counter.item())
     flat = flat / max(seen, 1)
     model.zero_grad(set_to_none=True)

@@ -1,4 +1,4 @@
-"""Seeding, logging and model bookkeeping helpers (pruning/utils.py:16-99)."""
+"""Seeding, device choice, logging and model bookkeeping helpers (pruning/utils.py:16-99)."""
 from __future__ import annotations
 
 import hashlib
@@ -10,25 +10,35 @@ import numpy as np
 import torch
 
 
-def set_random_seeds(seed: int = 42, deterministic: bool = True) -> None:
+def set_random_seeds(seed: int = 42) -> None:
     random.seed(seed)
     np.random.seed(seed)
     torch.manual_seed(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
-    if deterministic:
-        torch.backends.cudnn.deterministic = True
-        torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.deterministic = True
+    torch.backends.cudnn.benchmark = False
 
 
-def count_model_parameters(model: torch.nn.Module) -> int:
-    return sum(p.numel() for p in model.parameters())
+def get_device(device_str: Optional[str] = None) -> torch.device:
+    """None / "auto" pick the GPU when one is visible (pruning/utils.py:33-46)."""
+    if device_str in (None, "auto"):
+        device_str = "cuda" if torch.cuda.is_available() else "cpu"
+    return torch.device(device_str)
+
+
+def generate_config_hash(config_str: str) -> str:
+    """First 8 hex digits of the MD5 of the string (pruning/utils.py:49-59)."""
+    return hashlib.md5(config_str.encode()).hexdigest()[:8]
+
+
+def count_model_parameters(model: torch.nn.Module, only_trainable: bool = False) -> int:
+    return sum(p.numel() for p in model.parameters() if p.requires_grad or not only_trainable)
 
 
 def calculate_model_size_mb(model: torch.nn.Module) -> float:
-    n = sum(p.numel() * p.element_size() for p in model.parameters())
-    n += sum(b.numel() * b.element_size() for b in model.buffers())
-    return n / (1024 ** 2)
+    """Parameters at 4 bytes each, in MiB; buffers are not counted (pruning/utils.py:78-87)."""
+    return count_model_parameters(model) * 4 / (1024 * 1024)
 
 
 def model_checksum(model: torch.nn.Module, limit: Optional[int] = 8) -> str:

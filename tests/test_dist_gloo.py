@@ -101,3 +101,75 @@ def test_two_ranks_equal_one_rank(tmp_path):
         for r in two + [one]:
             np.testing.assert_allclose(r[f"taylor/{n}"], ty[f"tuple_all/{n}"], rtol=1e-5, atol=1e-9)
         np.testing.assert_array_equal(two[0][f"taylor/{n}"], two[1][f"taylor/{n}"])
+
+
+def _grad_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spice_amd import dist as sdist
+    from spice_amd.pruning.dataset import PruningDataHandler
+    from toy_models import ToyNet
+
+    torch.manual_seed(5)
+    net = ToyNet()
+    net.pw.bias.requires_grad_(False)             # a frozen parameter stays outside the buckets
+    data = torch.Generator().manual_seed(77)
+    xs = torch.randn(4, 3, 12, 12, generator=data)
+    ys = torch.randint(0, 4, (4, 12, 12), generator=data)
+    lo, hi = (rank * 4 // world, (rank + 1) * 4 // world)
+    buckets = sdist.FlatGradBuckets(net.parameters(), bucket_bytes=256)   # tiny: several buckets
+    opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=0.1)
+    n_buckets = len(buckets.buckets)
+    for it in range(2):                           # second pass checks zeroing and hook re-arming
+        net.train(it == 1)                        # pass 0 in eval mode: samples are independent
+        buckets.zero_grad()
+        loss = torch.nn.functional.cross_entropy(net(xs[lo:hi]), ys[lo:hi])
+        loss.backward()
+        buckets.finish()
+        if it == 0:
+            grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.requires_grad}
+        opt.step()
+    sdist.average_buffers_(net)
+    # loaders: the training split is dealt to the ranks without overlap, validation by stride
+    h = PruningDataHandler(data_root=os.path.join(out_dir, "nodata"), batch_size=2, seed=3, num_classes=4,
+                           input_size=(32, 32), synthetic_length=10)
+    train, val = h.get_train_val_loaders()
+    train_ids = [int(i) for i in train.sampler] if world > 1 else list(range(10))
+    val_ids = list(val.dataset.indices) if world > 1 else list(range(10))
+    cal_first = next(iter(h.get_calibration_dataloader()))[1][0, 0, :4].tolist()
+    np.savez(os.path.join(out_dir, f"grad_rank{rank}_of{world}.npz"), n_buckets=n_buckets,
+             train_ids=np.array(train_ids), val_ids=np.array(val_ids), cal_first=np.array(cal_first),
+             **{f"g/{k}": v.numpy() for k, v in grads.items()},
+             **{f"p/{k}": v.detach().numpy() for k, v in net.named_parameters()},
+             **{f"b/{k}": v.numpy() for k, v in net.named_buffers() if v.is_floating_point()})
+    buckets.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_gradient_buckets_average_over_ranks(tmp_path):
+    port = _free_port()
+    mp.spawn(_grad_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    one = np.load(os.path.join(tmp_path, "grad_rank0_of1.npz"))
+    port = _free_port()
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    two = [np.load(os.path.join(tmp_path, f"grad_rank{r}_of2.npz")) for r in range(2)]
+    assert int(two[0]["n_buckets"]) > 1
+    keys = [k for k in one.files if k.startswith("g/")]
+    assert keys and "g/pw.bias" not in keys
+    for k in keys:
+        # mean over the two half-batch gradients == full-batch gradient (eval-mode pass)
+        np.testing.assert_array_equal(two[0][k], two[1][k])
+        np.testing.assert_allclose(two[0][k], one[k], rtol=1e-4, atol=1e-7)
+    for k in [k for k in one.files if k.startswith("p/") or k.startswith("b/")]:
+        np.testing.assert_array_equal(two[0][k], two[1][k])   # replicas stay in lock step
+    # data sharding: disjoint, complete
+    tr = sorted(list(two[0]["train_ids"]) + list(two[1]["train_ids"]))
+    assert tr == list(range(10))
+    assert sorted(list(two[0]["val_ids"]) + list(two[1]["val_ids"])) == list(range(10))
+    assert not set(two[0]["val_ids"]) & set(two[1]["val_ids"])
+    np.testing.assert_array_equal(two[0]["cal_first"], two[1]["cal_first"])  # same calibration order on all ranks

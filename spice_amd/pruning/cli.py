@@ -37,13 +37,20 @@ def main(argv=None) -> None:
     try:
         args = parse_args(argv)
         config = build_config_from_args(args)
+        # under torch.distributed.run: one process per GPU, rank-local device
+        from .. import dist as sdist
+        rank, world, local = sdist.init_from_env()
+        if world > 1 and config.device == "cuda":
+            config.device = f"cuda:{local}"
         logger.info(f"Starting structured pruning: model={config.model_name} strategy={config.pruning_strategy} "
                     f"ratio={config.pruning_ratio} steps={config.iterative_steps} device={config.device} "
                     f"output={config.output_dir}")
         if config.enable_kd_lite:
             logger.info(f"  KD-Lite: T={config.kd_temperature} alpha={config.kd_alpha} data={config.kd_data_ratio}")
         from .pruner import prune_model
-        _print_summary(prune_model(config))
+        results = prune_model(config)
+        if rank == 0:
+            _print_summary(results)
     except KeyboardInterrupt:
         logger.info("Pruning interrupted by user")
         sys.exit(1)

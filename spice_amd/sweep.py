@@ -15,6 +15,7 @@ is combined with one all-reduce.
 """
 from __future__ import annotations
 
+import contextlib
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -86,6 +87,18 @@ class SensitivitySweep:
         for i, j, st in zip(todo, jobs, starts):
             self.jobs[i] = j.build(idx_device=shared, idx_start=st, with_grads=False)
 
+    @contextlib.contextmanager
+    def session(self):
+        """One autocast region around a whole run of candidates.  Autocast keeps the fp16 copies of
+        fp32 parameters it has cast until its OUTERMOST region exits; the per-forward regions nest
+        inside this one, so the ~70 unchanged convolution weights are cast once per sweep instead of
+        once per candidate (the same fp16 values either way)."""
+        if self.autocast_dtype is None:
+            yield self
+        else:
+            with torch.autocast("cuda", dtype=self.autocast_dtype):
+                yield self
+
     def forward(self, images: torch.Tensor) -> torch.Tensor:
         with torch.no_grad():
             if self.autocast_dtype is not None:
@@ -132,10 +145,11 @@ class SensitivitySweep:
         c = self.num_classes
         table = torch.zeros(n, c, c, dtype=torch.int64, device=self.device)
         kd = torch.zeros(n, 3, dtype=torch.float32, device=self.device)
-        teacher = self.forward(images).float().contiguous() if with_kd else None
-        sdist.sharded_tables(n, indices, costs,
-                             lambda i: self.evaluate(i, images, labels, teacher, table[i], kd[i] if with_kd else None),
-                             [table, kd] if with_kd else [table])
+        with self.session():
+            teacher = self.forward(images).float().contiguous() if with_kd else None
+            sdist.sharded_tables(n, indices, costs,
+                                 lambda i: self.evaluate(i, images, labels, teacher, table[i], kd[i] if with_kd else None),
+                                 [table, kd] if with_kd else [table])
         return {"confusion": table, "kd": kd, "miou": miou_from_confusion(table)}
 
 

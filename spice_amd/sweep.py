@@ -22,6 +22,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import dist as sdist
 from . import ops
@@ -71,6 +72,7 @@ class SensitivitySweep:
         self.jobs: Dict[int, SliceJob] = {}
         # when set to a list, evaluate() appends a (start, end) HIP event pair around each KD-Lite launch
         self.kd_events: Optional[list] = None
+        self._geometry, self._geometry_for, self._warmed = {}, None, set()
 
     # -- host preparation for a set of candidates: plans + one shared index upload
     def prepare(self, indices: Sequence[int]) -> None:
@@ -98,6 +100,56 @@ class SensitivitySweep:
         else:
             with torch.autocast("cuda", dtype=self.autocast_dtype):
                 yield self
+
+    def warm_shapes(self, images: torch.Tensor, indices: Sequence[int]) -> int:
+        """Run one throw-away convolution for every NEW convolution problem (changed channel
+        counts) the candidates in `indices` will bring, before any of them is evaluated.
+        MIOpen's solver lookup for a problem it has not seen in this process synchronises the
+        stream; inside the candidate loop that drains the queue of launches the host has built up
+        (about 1.5 ms per candidate on MI355X), here nothing is queued yet (about 0.4 ms per problem).
+        Doing the lookups on a helper thread instead does not pay: they wait for the device queue the
+        evaluation loop keeps full, and the loop ends up waiting for the helper.  Returns the number
+        of problems warmed."""
+        shape = tuple(images.shape)
+        if self._geometry_for != shape:
+            self._geometry = {}
+            hooks = [m.register_forward_hook(
+                lambda mod, inp, out: self._geometry.__setitem__(mod, (tuple(inp[0].shape), inp[0].dtype)))
+                for m in self.model.modules() if isinstance(m, nn.Conv2d)]
+            try:
+                with self.session():
+                    self.forward(images)
+            finally:
+                for h in hooks:
+                    h.remove()
+            self._geometry_for = shape
+        warmed = 0
+        for i in indices:
+            if i not in self.jobs:
+                self.prepare([i])
+            warmed += self._warm_candidate(i)
+        return warmed
+
+    def _warm_candidate(self, i: int) -> int:
+        warmed = 0
+        for mod, upd in self.jobs[i].attr_updates:
+            if not isinstance(mod, nn.Conv2d) or mod not in self._geometry:
+                continue
+            (n, _, h, w), in_dtype = self._geometry[mod]
+            cin = upd.get("in_channels", mod.in_channels)
+            cout = upd.get("out_channels", mod.out_channels)
+            groups = upd.get("groups", mod.groups)
+            key = (n, cin, h, w, cout, groups, mod.kernel_size, mod.stride, mod.padding, mod.dilation)
+            if key in self._warmed or groups == cin:  # depthwise convolutions do not go through MIOpen
+                continue
+            self._warmed.add(key)
+            dt = self.autocast_dtype or in_dtype
+            x = torch.empty(n, cin, h, w, device=self.device, dtype=dt)
+            wt = torch.empty(cout, cin // groups, *mod.kernel_size, device=self.device, dtype=dt)
+            with torch.no_grad():
+                F.conv2d(x, wt, None, mod.stride, mod.padding, mod.dilation, groups)
+            warmed += 1
+        return warmed
 
     def forward(self, images: torch.Tensor) -> torch.Tensor:
         with torch.no_grad():
@@ -141,7 +193,9 @@ class SensitivitySweep:
         rank, world = sdist.world()
         costs = [self.candidates[i].cost for i in indices]
         parts = sdist.partition_by_cost(costs, world)
-        self.prepare([indices[k] for k in parts[rank]])
+        mine = [indices[k] for k in parts[rank]]
+        self.prepare(mine)
+        self.warm_shapes(images, mine)
         c = self.num_classes
         table = torch.zeros(n, c, c, dtype=torch.int64, device=self.device)
         kd = torch.zeros(n, 3, dtype=torch.float32, device=self.device)

@@ -3,9 +3,14 @@ loop, so the figures are enqueue costs), and the device-side total."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from spice_amd import miopen_tuning
+if os.environ.get("TUNE", "1") == "1":
+    print("tune s", miopen_tuning.ensure_tuned("DeepLabV3Plus", "resnet50", 21, 8, 512, "fp16"), flush=True)
 from spice_amd import nets, ops, synth
 from spice_amd.sweep import DEFAULT_RATIOS, SensitivitySweep
 
+if os.environ.get("IMMEDIATE") == "1":
+    torch.backends.miopen.immediate = True
 dev = torch.device("cuda:0")
 torch.manual_seed(1234)
 C = 21

@@ -20,6 +20,7 @@ namespace spice {
 constexpr int kKdThreads = 256;
 constexpr int kKdMaxBlocks = 2048;  // capacity of the partial-sum tables in the workspace
 constexpr int kKdDefaultBlocks = 512;  // two workgroups per CU, each looping over its tiles
+constexpr size_t kKdMaxStageBytes = 48 * 1024;  // LDS stage of the gradient pass (C <= 24)
 constexpr float kNegFill = -1.0e30f;
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
@@ -231,23 +232,34 @@ struct PixStats {
     float ms[VEC], mt[VEC], zs[VEC], z1[VEC], zt[VEC], zt1[VEC], at[VEC], sy[VEC];
 };
 
-// Fold four class planes (c0..c0+3) into the running softmax statistics of VEC pixels.
-// FULL = all four classes exist; otherwise loads are clamped to the last class and the
-// surplus values replaced by a large negative fill (their exponentials are exactly zero).
-template <int VEC, bool FULL, bool CONF>
-__device__ __forceinline__ void kd_fold4(PixStats<VEC> &st, const float *__restrict__ s_img,
-                                         const float *__restrict__ t_img, long long HW, int r,
-                                         int c0, int C, const int (&id)[VEC], float k2) {
-    float sv[4][VEC], tv[4][VEC];
+// Fold U class planes (c0..c0+U-1) into the running softmax statistics of VEC pixels.
+// FULL = all U classes exist; otherwise loads are clamped to the last class and the surplus
+// values replaced by a large negative fill (their exponentials are exactly zero).
+// STAGE: the raw logits are also parked in LDS (slot (2c+which)*threads + tid, touched by this
+// thread only) for the gradient pass.
+template <int VEC, int U, bool FULL, bool CONF, bool STAGE>
+__device__ __forceinline__ void kd_fold(PixStats<VEC> &st, const float *__restrict__ s_img,
+                                        const float *__restrict__ t_img, long long HW, int r,
+                                        int c0, int C, const int (&id)[VEC], float k2,
+                                        typename VecF<VEC>::type *stage) {
+    float sv[U][VEC], tv[U][VEC];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
         const int cc = FULL ? c0 + u : min(c0 + u, C - 1);
         load_vec<VEC>(s_img + (long long)cc * HW + r, sv[u]);
         load_vec<VEC>(t_img + (long long)cc * HW + r, tv[u]);
     }
+    if (STAGE) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!FULL && c0 + u >= C) break;
+            store_vec<VEC>(reinterpret_cast<float *>(stage + (2 * (c0 + u)) * kKdThreads + threadIdx.x), sv[u]);
+            store_vec<VEC>(reinterpret_cast<float *>(stage + (2 * (c0 + u) + 1) * kKdThreads + threadIdx.x), tv[u]);
+        }
+    }
     if (!FULL) {
 #pragma unroll
-        for (int u = 1; u < 4; ++u) {
+        for (int u = 1; u < U; ++u) {
             const bool gone = c0 + u >= C;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
@@ -258,8 +270,13 @@ __device__ __forceinline__ void kd_fold4(PixStats<VEC> &st, const float *__restr
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        const float msn = fmaxf(fmaxf(st.ms[e], fmaxf(sv[0][e], sv[1][e])), fmaxf(sv[2][e], sv[3][e]));
-        const float mtn = fmaxf(fmaxf(st.mt[e], fmaxf(tv[0][e], tv[1][e])), fmaxf(tv[2][e], tv[3][e]));
+        float msn = fmaxf(fmaxf(st.ms[e], fmaxf(sv[0][e], sv[1 % U][e])), fmaxf(sv[2 % U][e], sv[3 % U][e]));
+        float mtn = fmaxf(fmaxf(st.mt[e], fmaxf(tv[0][e], tv[1 % U][e])), fmaxf(tv[2 % U][e], tv[3 % U][e]));
+#pragma unroll
+        for (int u = 4; u < U; u += 2) {
+            msn = fmaxf(msn, fmaxf(sv[u][e], sv[(u + 1) % U][e]));
+            mtn = fmaxf(mtn, fmaxf(tv[u][e], tv[(u + 1) % U][e]));
+        }
         const float ds = st.ms[e] - msn;  // <= 0
         const float dt = st.mt[e] - mtn;  // <= 0
         const float rt = fast_exp2(dt * k2);
@@ -271,7 +288,7 @@ __device__ __forceinline__ void kd_fold4(PixStats<VEC> &st, const float *__restr
         if (CONF) Zt1 = st.zt1[e] * fast_exp2(dt * kLog2e);
         float sy = st.sy[e];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const float sc = sv[u][e] - msn;
             const float tc = tv[u][e] - mtn;
             const float et = fast_exp2(tc * k2);
@@ -294,19 +311,25 @@ __device__ __forceinline__ void kd_fold4(PixStats<VEC> &st, const float *__restr
 }
 
 // Gradient of four class planes: softmax probabilities recomputed from the final statistics.
-template <int VEC, bool FULL>
+template <int VEC, bool FULL, bool STAGE>
 __device__ __forceinline__ void kd_grad4(const PixStats<VEC> &st, const float *__restrict__ s_img,
                                          const float *__restrict__ t_img, float *__restrict__ g_img,
                                          long long HW, int r, int c0, int C, const int (&id)[VEC],
                                          float k2, const float (&gce)[VEC], const float (&gkd)[VEC],
                                          const float (&izs)[VEC], const float (&iz1)[VEC],
-                                         const float (&izt)[VEC]) {
+                                         const float (&izt)[VEC],
+                                         const typename VecF<VEC>::type *stage) {
     float sv[4][VEC], tv[4][VEC];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int cc = FULL ? c0 + u : min(c0 + u, C - 1);
-        load_vec<VEC>(s_img + (long long)cc * HW + r, sv[u]);
-        load_vec<VEC>(t_img + (long long)cc * HW + r, tv[u]);
+        if (STAGE) {
+            load_vec<VEC>(reinterpret_cast<const float *>(stage + (2 * cc) * kKdThreads + threadIdx.x), sv[u]);
+            load_vec<VEC>(reinterpret_cast<const float *>(stage + (2 * cc + 1) * kKdThreads + threadIdx.x), tv[u]);
+        } else {
+            load_vec<VEC>(s_img + (long long)cc * HW + r, sv[u]);
+            load_vec<VEC>(t_img + (long long)cc * HW + r, tv[u]);
+        }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -375,8 +398,13 @@ __device__ __forceinline__ void kd_finalize(const double *partial, int n_blocks,
     }
 }
 
-template <int VEC, bool GRAD, bool EXT>
+// STAGE (gradient only): the tile's logits are parked in dynamic LDS during the statistics pass
+// and the gradient pass reads them from there instead of from memory.
+template <int VEC, bool GRAD, bool EXT, bool STAGE>
 __global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
+    extern __shared__ float4 stage_raw[];
+    typename VecF<VEC>::type *stage = reinterpret_cast<typename VecF<VEC>::type *>(stage_raw);
+    constexpr int U = STAGE ? 8 : 4;  // class planes per step (loads in flight: 2U per lane)
     __shared__ double red[kKdThreads / 64][8];
     __shared__ double norm[4];
     const int tid = threadIdx.x;
@@ -412,6 +440,7 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
     const TileGeom tg = tile_geom<VEC>(a);
     const int C = a.C;
     const int C4 = C & ~3;
+    const int CU = (C / U) * U;
     for (int tile = blockIdx.x; tile < tg.n_tiles; tile += gridDim.x) {
         const int n = tile / tg.tiles_per_img;
         const int qi = (tile - n * tg.tiles_per_img) * kKdThreads + tid;
@@ -431,12 +460,14 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
         }
         if (use_c) {
 #pragma unroll 1
-            for (int c0 = 0; c0 < C4; c0 += 4) kd_fold4<VEC, true, true>(st, s_img, t_img, a.HW, r, c0, C, id, k2);
-            if (C4 < C) kd_fold4<VEC, false, true>(st, s_img, t_img, a.HW, r, C4, C, id, k2);
+            for (int c0 = 0; c0 < CU; c0 += U)
+                kd_fold<VEC, U, true, true, STAGE>(st, s_img, t_img, a.HW, r, c0, C, id, k2, stage);
+            if (CU < C) kd_fold<VEC, U, false, true, STAGE>(st, s_img, t_img, a.HW, r, CU, C, id, k2, stage);
         } else {
 #pragma unroll 1
-            for (int c0 = 0; c0 < C4; c0 += 4) kd_fold4<VEC, true, false>(st, s_img, t_img, a.HW, r, c0, C, id, k2);
-            if (C4 < C) kd_fold4<VEC, false, false>(st, s_img, t_img, a.HW, r, C4, C, id, k2);
+            for (int c0 = 0; c0 < CU; c0 += U)
+                kd_fold<VEC, U, true, false, STAGE>(st, s_img, t_img, a.HW, r, c0, C, id, k2, stage);
+            if (CU < C) kd_fold<VEC, U, false, false, STAGE>(st, s_img, t_img, a.HW, r, CU, C, id, k2, stage);
         }
 
         float wy[VEC], wkd[VEC];
@@ -497,9 +528,9 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
             float *g_img = a.grad + (long long)n * C * a.HW;
 #pragma unroll 1
             for (int c0 = 0; c0 < C4; c0 += 4)
-                kd_grad4<VEC, true>(st, s_img, t_img, g_img, a.HW, r, c0, C, id, k2, gce, gkd, izs, iz1, izt);
+                kd_grad4<VEC, true, STAGE>(st, s_img, t_img, g_img, a.HW, r, c0, C, id, k2, gce, gkd, izs, iz1, izt, stage);
             if (C4 < C)
-                kd_grad4<VEC, false>(st, s_img, t_img, g_img, a.HW, r, C4, C, id, k2, gce, gkd, izs, iz1, izt);
+                kd_grad4<VEC, false, STAGE>(st, s_img, t_img, g_img, a.HW, r, C4, C, id, k2, gce, gkd, izs, iz1, izt, stage);
         }
     }
     if (bad) atomicAdd(reinterpret_cast<unsigned long long *>(a.bad), (unsigned long long)bad);
@@ -566,6 +597,25 @@ static int kd_max_blocks() {
     return (v >= 1 && v <= kKdMaxBlocks) ? v : kKdDefaultBlocks;
 }
 
+constexpr size_t kLdsPerCu = 160 * 1024;
+
+static int device_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
+static int kd_stage_mode() {
+    const char *e = getenv("SPICE_KD_STAGE");  // tuning knob: 0 = never stage the gradient pass in LDS
+    return e ? atoi(e) : 1;
+}
+
 template <int VEC>
 static int kd_launch(const KdArgs &a, bool grad, bool ext, int blocks, hipStream_t st) {
     const dim3 g(blocks), b(kKdThreads);
@@ -576,15 +626,37 @@ static int kd_launch(const KdArgs &a, bool grad, bool ext, int blocks, hipStream
             hipLaunchKernelGGL((kdlite_prepass_kernel<VEC, false>), dim3(a.pre_blocks), b, 0, st, a);
         SPICE_LAUNCH_CHECK();
         if (ext)
-            hipLaunchKernelGGL((kdlite_main_kernel<VEC, true, true>), g, b, 0, st, a);
+            hipLaunchKernelGGL((kdlite_main_kernel<VEC, true, true, false>), g, b, 0, st, a);
         else
-            hipLaunchKernelGGL((kdlite_main_kernel<VEC, true, false>), g, b, 0, st, a);
+            hipLaunchKernelGGL((kdlite_main_kernel<VEC, true, false, false>), g, b, 0, st, a);
     } else {
         if (ext)
-            hipLaunchKernelGGL((kdlite_main_kernel<VEC, false, true>), g, b, 0, st, a);
+            hipLaunchKernelGGL((kdlite_main_kernel<VEC, false, true, false>), g, b, 0, st, a);
         else
-            hipLaunchKernelGGL((kdlite_main_kernel<VEC, false, false>), g, b, 0, st, a);
+            hipLaunchKernelGGL((kdlite_main_kernel<VEC, false, false, false>), g, b, 0, st, a);
     }
+    SPICE_LAUNCH_CHECK();
+    return SPICE_OK;
+}
+
+// Gradient with the logits staged in LDS: one pixel per lane, so a workgroup's stage is
+// C * 2 * 256 * 4 bytes (43 KB at 21 classes: three workgroups per CU).
+static int kd_launch_staged(const KdArgs &a, bool ext, bool vec4, int blocks, size_t lds_bytes, hipStream_t st) {
+    const dim3 g(blocks), b(kKdThreads);
+    if (vec4) {  // the label pre-pass keeps its 16-byte accesses when the layout allows
+        if (ext)
+            hipLaunchKernelGGL((kdlite_prepass_kernel<4, true>), dim3(a.pre_blocks), b, 0, st, a);
+        else
+            hipLaunchKernelGGL((kdlite_prepass_kernel<4, false>), dim3(a.pre_blocks), b, 0, st, a);
+    } else if (ext)
+        hipLaunchKernelGGL((kdlite_prepass_kernel<1, true>), dim3(a.pre_blocks), b, 0, st, a);
+    else
+        hipLaunchKernelGGL((kdlite_prepass_kernel<1, false>), dim3(a.pre_blocks), b, 0, st, a);
+    SPICE_LAUNCH_CHECK();
+    if (ext)
+        hipLaunchKernelGGL((kdlite_main_kernel<1, true, true, true>), g, b, lds_bytes, st, a);
+    else
+        hipLaunchKernelGGL((kdlite_main_kernel<1, true, false, true>), g, b, lds_bytes, st, a);
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;
 }
@@ -656,6 +728,27 @@ extern "C" int spice_kdlite_forward(const float *student, const float *teacher, 
     a.coef_kd = coef_kd;
     a.conf = params->confidence_weight != 0;
 
+    const size_t stage_bytes = (size_t)c * 2 * kKdThreads * sizeof(float);
+    if (grad != nullptr && kd_stage_mode() != 0 && stage_bytes <= kKdMaxStageBytes) {
+        int64_t b1 = n * ceil_div(hw, kKdThreads);  // tiles at one pixel per lane
+        if (b1 > INT32_MAX) return SPICE_ERR_UNSUPPORTED;
+        if (b1 < 1) b1 = 1;
+        {
+            // exactly the workgroups that are resident at once (LDS-limited), each looping over
+            // its tiles: measured best on MI355X (768: 121 us, 1536: 130 us, 2048: 138 us)
+            int64_t per_cu = (int64_t)(kLdsPerCu / (stage_bytes + 1024));
+            if (per_cu > 8) per_cu = 8;
+            if (per_cu < 1) per_cu = 1;
+            int64_t lim = per_cu * device_cu_count();
+            const char *e = getenv("SPICE_KD_STAGE_BLOCKS");  // tuning knob
+            const int cap = e ? atoi(e) : 0;
+            if (cap >= 1) lim = cap;
+            if (lim > kKdMaxBlocks) lim = kKdMaxBlocks;
+            if (b1 > lim) b1 = lim;
+        }
+        a.pre_blocks = (int)b1;
+        return kd_launch_staged(a, ext, vec4, (int)b1, stage_bytes, st);
+    }
     return vec4 ? kd_launch<4>(a, grad != nullptr, ext, (int)blocks, st)
                 : kd_launch<1>(a, grad != nullptr, ext, (int)blocks, st);
 }

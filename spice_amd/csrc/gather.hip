@@ -3,10 +3,18 @@
 // copied with 16-byte accesses when no input-channel list breaks their contiguity.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace spice {
 
 constexpr int kGatherThreads = 256;
-constexpr int64_t kGatherTargetElems = 16384;
+constexpr int64_t kGatherDefaultTargetElems = 16384;
+
+static int64_t gather_target_elems() {
+    const char *e = getenv("SPICE_GATHER_TARGET_ELEMS");  // tuning knob (host side only)
+    const long v = e ? atol(e) : 0;
+    return (v >= 256 && v <= (1 << 22)) ? v : kGatherDefaultTargetElems;
+}
 
 __global__ __launch_bounds__(kGatherThreads) void gather_kernel(
     const unsigned *__restrict__ src_base, unsigned *__restrict__ dst_base,
@@ -83,6 +91,7 @@ extern "C" int64_t spice_gather_plan(const spice_gather_desc *tensors, int32_t n
                                      spice_gather_item *items, int64_t capacity) {
     if (n_tensors < 0 || (n_tensors > 0 && tensors == nullptr)) return -SPICE_ERR_ARG;
     int64_t n = 0;
+    const int64_t target = gather_target_elems();
     for (int32_t t = 0; t < n_tensors; ++t) {
         const spice_gather_desc &d = tensors[t];
         if (d.dst_rows < 0 || d.dst_cols < 0 || d.src_cols < 0 || d.inner < 1 || d.src_off < 0 ||
@@ -101,7 +110,7 @@ extern "C" int64_t spice_gather_plan(const spice_gather_desc *tensors, int32_t n
         int L = kWave;
         while (L > 1 && L > units) L >>= 1;
         const int64_t groups = kGatherThreads / L;
-        int64_t rpi = kGatherTargetElems / row_len;
+        int64_t rpi = target / row_len;
         if (rpi < 1) rpi = 1;
         rpi = ceil_div(rpi, groups) * groups;
         const int64_t n_it = ceil_div(d.dst_rows, rpi);

@@ -314,10 +314,10 @@ def main():
                    "groups": len(sweep.groups), "ratios": list(DEFAULT_RATIOS),
                    "forward": "fp32" if args.fp32_forward else "fp16 autocast (MIOpen)",
                    "kd": {"T": 4.0, "alpha": 0.7}, "parallelism": f"candidates sharded over {world} rank(s)"},
-        "roofline": {"bound": "hbm", "kernel": "spice::kdlite_main_kernel<4,false,false> (one launch per "
+        "roofline": {"bound": "hbm", "kernel": "spice::kdlite_main_kernel<4,false,false,false> (one launch per "
                      "spice_kdlite_forward call)", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS,
                      "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4),
-                     "traffic": pmc_traffic("spice::kdlite_main_kernel<4, false, false>"),
+                     "traffic": pmc_traffic("spice::kdlite_main_kernel<4, false, false, false>"),
                      "algorithmic_bytes_per_launch": kd_bytes, "avg_launch_us": round(1e3 * kd_ms, 2),
                      "launches_timed": len(kd_events)},
         "setup": {"miopen_find_db_warmup_s": round(tune_s, 1), "timed_prepare_s": round(prep_s, 4), "warm_mode": args.warm_mode,

@@ -8,8 +8,10 @@ itself only runs the one-shot Taylor analysis (pruning/pruning_core.py:99-133).
 
 Per candidate the device sees: one gather launch (slice the group's tensors), the forward of the
 sliced network (MIOpen), one fused arg-max + histogram launch, one fused KD-Lite launch pair.
-Everything the host has to prepare (kept-index lists, launch plans) is built and uploaded for the
-whole sweep before the first candidate runs, so the candidate loop only enqueues work.
+Everything the host has to prepare (kept-index lists, launch plans, MIOpen's solver lookups for
+the convolution shapes the candidates will bring) is done for a rank's whole share before its
+first candidate runs, and the fp16 copies of the unchanged weights are made once per sweep, so
+the candidate loop only enqueues work and the device queue never drains.
 Candidates are independent: ranks evaluate disjoint subsets and the [n_candidates, C, C] table
 is combined with one all-reduce.
 """

@@ -8,7 +8,7 @@ pruning/pruning_core.py:143-145, pruning/strategies.py:53); torch-pruning is abs
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable, List, Optional, Sequence
+from typing import Dict, Iterable, Sequence
 
 import numpy as np
 import torch

@@ -48,7 +48,8 @@ def _compare_models(gpu_model, cpu_model):
 
 
 @pytest.mark.parametrize("arch,enc", [("DeepLabV3Plus", "resnet50"), ("Unet", "timm-efficientnet-b3"),
-                                      ("Unet", "resnet50")])
+                                      ("Unet", "resnet50"), ("FPN", "resnet50"), ("FPN", "timm-efficientnet-b3"),
+                                      ("DeepLabV3Plus", "timm-efficientnet-b3")])
 def test_local_steps_match_oracle(dev, arch, enc):
     base = _make(arch, enc)
     cpu = copy.deepcopy(base)

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 from torch.utils.data import DataLoader
 
+from ... import dist as sdist
 from .metrics import compute_metrics_from_confusion, update_confusion_matrix_from_logits
 
 
@@ -22,20 +23,31 @@ def _split_batch(batch, device):
 
 
 @torch.no_grad()
-def inference(model: nn.Module, test_loader: DataLoader, device: torch.device, num_classes: int = 5):
-    """-> {"miou", "mean_acc", "per_class_iou", "per_class_acc"}."""
+def inference(model: nn.Module, test_loader: DataLoader, device: torch.device, num_classes: int = 5,
+              shard: bool = True):
+    """-> {"miou", "mean_acc", "per_class_iou", "per_class_acc"}.
+
+    With torch.distributed initialised (one process per GPU) and `shard`, every rank iterates the
+    same loader, evaluates the batches whose index is congruent to its rank, and the [C,C] int64
+    matrices are summed with one all-reduce: integer counts, so every rank ends with exactly the
+    single-process matrix whatever the order."""
     device = torch.device(device)
     if hasattr(model, "eval"):
         model.eval()
     model = model.to(device)
     conf = torch.zeros(num_classes, num_classes, dtype=torch.long, device=device)
+    rank, world = sdist.world() if shard else (0, 1)
     with torch.amp.autocast(device.type, enabled=(device.type == "cuda")):
-        for batch in test_loader:
+        for k, batch in enumerate(test_loader):
+            if k % world != rank:
+                continue
             images, masks = _split_batch(batch, device)
             outputs = model(images)
             if isinstance(outputs, dict):
                 outputs = outputs.get("out", outputs.get("logits", outputs))
             update_confusion_matrix_from_logits(conf, outputs, masks, num_classes)
+    if world > 1:
+        sdist.all_reduce_sum_(conf)
     iou, acc, miou = compute_metrics_from_confusion(conf)
     return {"miou": miou, "mean_acc": float(np.mean(acc)), "per_class_iou": iou.tolist(),
             "per_class_acc": acc.tolist()}

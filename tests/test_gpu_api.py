@@ -252,3 +252,24 @@ def test_two_rank_prune_and_finetune(dev, tmp_path):
     run_dir = tmp_path / "UNET_resnet_magnitude_taylor_0.40_kd"
     for f in ("final_model.pth", "metrics.json", "model_info.txt", "hybrid_pruning_report.json"):
         assert (run_dir / f).exists(), f
+
+
+def test_two_rank_sharded_evaluation(dev, tmp_path):
+    """Evaluation batches dealt to two ranks + one all-reduce of the int64 confusion matrix give
+    every rank exactly the single-process metrics."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(__file__), "ddp_eval_worker.py")
+    one = subprocess.run([sys.executable, worker, str(tmp_path)], capture_output=True, text=True, timeout=300,
+                         env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    env = dict(os.environ, SPICE_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29534", worker, str(tmp_path)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+    ref = json.load(open(tmp_path / "eval_rank0_of1.json"))
+    for r in range(2):
+        got = json.load(open(tmp_path / f"eval_rank{r}_of2.json"))
+        assert got == ref
+    assert 0.0 <= ref["miou"] <= 1.0 and len(ref["per_class_iou"]) == 6

@@ -88,18 +88,21 @@ def main():
                    for w, g in zip(ws, gs)]
             report("importance_taylor", timed(fns, args.iters), plan.algorithmic_bytes(nat.IMP_TAYLOR))
         if want("gather"):
-            specs, idx, dpos, ipos = [], [], 0, 0
-            for (o, i, kh, kw), off in zip(shapes, offs):
-                ko = np.arange(0, o, 2, dtype=np.int64)
-                specs.append(ops.GatherSpec(off, dpos, ipos, -1, len(ko), i, i, kh * kw))
-                idx.append(ko)
-                ipos += len(ko)
-                dpos += (len(ko) * i * kh * kw + 3) // 4 * 4
-            gplan = ops.GatherPlan(specs, dev)
-            idx_t = torch.from_numpy(np.concatenate(idx)).to(dev)
-            dsts = [torch.empty(dpos, device=dev) for _ in range(copies)]
-            fns = [lambda w=w, d=d: gplan.run(w.data_ptr(), d.data_ptr(), idx_t.data_ptr()) for w, d in zip(ws, dsts)]
-            report(f"gather_out50 ({gplan.n_items} items)", timed(fns, args.iters), gplan.algorithmic_bytes())
+            for label, pick in (("gather_out50", lambda o: np.arange(0, o, 2, dtype=np.int64)),
+                                ("gather_first_half", lambda o: np.arange(0, (o + 1) // 2, dtype=np.int64))):
+                specs, idx, dpos, ipos = [], [], 0, 0
+                for (o, i, kh, kw), off in zip(shapes, offs):
+                    ko = pick(o)
+                    specs.append(ops.GatherSpec(off, dpos, ipos, -1, len(ko), i, i, kh * kw))
+                    idx.append(ko)
+                    ipos += len(ko)
+                    dpos += (len(ko) * i * kh * kw + 3) // 4 * 4
+                gplan = ops.GatherPlan(specs, dev)
+                idx_t = torch.from_numpy(np.concatenate(idx)).to(dev)
+                dsts = [torch.empty(dpos, device=dev) for _ in range(copies)]
+                fns = [lambda w=w, d=d: gplan.run(w.data_ptr(), d.data_ptr(), idx_t.data_ptr()) for w, d in zip(ws, dsts)]
+                report(f"{label} ({gplan.n_items} items)", timed(fns, args.iters), gplan.algorithmic_bytes())
+                del dsts
         del ws, gs
 
     if want("kdlite") or want("kdlite_grad"):

@@ -5,6 +5,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace spice {
 
 constexpr int kGatherThreads = 256;
@@ -16,16 +18,81 @@ static int64_t gather_target_elems() {
     return (v >= 256 && v <= (1 << 22)) ? v : kGatherDefaultTargetElems;
 }
 
+// Element gather of one work item: the same flat walk over the destination as the whole-row
+// path, four consecutive 32-bit words per lane and two such quads per pass, so stores stay
+// contiguous (one 16-byte store per lane where the item's destination is 16-byte aligned) while
+// each word comes from src[keep_out[row], keep_in[col], k].  The presence of each list is a
+// template parameter so that nothing inside a pass is conditional: all row/column ids of a pass are
+// loaded first, then its eight words, then they are stored.
+template <bool HAS_OUT, bool HAS_IN>
+__device__ __forceinline__ void gather_words(const spice_gather_item &it, const unsigned *__restrict__ src,
+                                             unsigned *__restrict__ dst, const long long *__restrict__ idx_out,
+                                             const long long *__restrict__ idx_in, bool st4) {
+    const int tid = threadIdx.x;
+    const int row_len = it.dst_cols * it.inner;
+    const int inner = it.inner;
+    const int64_t src_row_stride = (int64_t)it.src_cols * inner;
+    const int total = it.n_rows * row_len;
+
+    auto locate = [&](int e, int &row, int &i, int &k) {
+        row = e / row_len;
+        const int rem = e - row * row_len;
+        i = inner == 1 ? rem : rem / inner;
+        k = rem - i * inner;
+    };
+    auto fetch_n = [&](int e0, int stride, unsigned *v, auto n_tag) {
+        constexpr int N = decltype(n_tag)::value;
+        int row[N], i[N], k[N];
+        long long so[N], ci[N];
+#pragma unroll
+        for (int u = 0; u < N; ++u) locate(e0 + (u >> 2) * stride + (u & 3), row[u], i[u], k[u]);
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            so[u] = HAS_OUT ? idx_out[row[u]] : (long long)(it.row0 + row[u]);
+            ci[u] = HAS_IN ? idx_in[i[u]] : (long long)i[u];
+        }
+#pragma unroll
+        for (int u = 0; u < N; ++u) v[u] = src[so[u] * src_row_stride + ci[u] * inner + k[u]];
+    };
+    using N8 = std::integral_constant<int, 8>;
+    using N4 = std::integral_constant<int, 4>;
+
+    int e0 = tid * 4;
+    if (st4) {
+        for (; e0 + 3 + 4 * kGatherThreads < total; e0 += 8 * kGatherThreads) {
+            unsigned v[8];
+            fetch_n(e0, 4 * kGatherThreads, v, N8{});
+            *reinterpret_cast<uint4 *>(dst + e0) = make_uint4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<uint4 *>(dst + e0 + 4 * kGatherThreads) = make_uint4(v[4], v[5], v[6], v[7]);
+        }
+        for (; e0 + 3 < total; e0 += 4 * kGatherThreads) {
+            unsigned v[4];
+            fetch_n(e0, 0, v, N4{});
+            *reinterpret_cast<uint4 *>(dst + e0) = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    } else {
+        for (; e0 + 3 < total; e0 += 4 * kGatherThreads) {
+            unsigned v[4];
+            fetch_n(e0, 0, v, N4{});
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dst[e0 + u] = v[u];
+        }
+    }
+    for (int e = e0; e < total && e < e0 + 4; ++e) {  // at most three words of one lane
+        int row, i, k;
+        locate(e, row, i, k);
+        const long long so = HAS_OUT ? idx_out[row] : (long long)(it.row0 + row);
+        const long long ci = HAS_IN ? idx_in[i] : (long long)i;
+        dst[e] = src[so * src_row_stride + ci * inner + k];
+    }
+}
+
 __global__ __launch_bounds__(kGatherThreads) void gather_kernel(
     const unsigned *__restrict__ src_base, unsigned *__restrict__ dst_base,
     const long long *__restrict__ idx_base, const spice_gather_item *__restrict__ items,
     int bases_vec_ok) {
     const spice_gather_item it = items[blockIdx.x];
-    const int L = it.lanes;
     const int tid = threadIdx.x;
-    const int sub = tid / L;
-    const int lane = tid & (L - 1);
-    const int groups = kGatherThreads / L;
     const int row_len = it.dst_cols * it.inner;
     const int64_t src_row_stride = (int64_t)it.src_cols * it.inner;
     const unsigned *src = src_base + it.src_off;
@@ -71,22 +138,14 @@ __global__ __launch_bounds__(kGatherThreads) void gather_kernel(
         }
         return;
     }
-    for (int r = sub; r < it.n_rows; r += groups) {
-        const int64_t so = idx_out ? (int64_t)idx_out[r] : (int64_t)(it.row0 + r);
-        const unsigned *srow = src + so * src_row_stride;
-        unsigned *drow = dst + (int64_t)r * row_len;
-        if (idx_in == nullptr) {
-            for (int j = lane; j < row_len; j += L) drow[j] = srow[j];
-        } else if (it.inner == 1) {
-            for (int j = lane; j < row_len; j += L) drow[j] = srow[idx_in[j]];
-        } else {
-            const int inner = it.inner;
-            for (int j = lane; j < row_len; j += L) {
-                const int i = j / inner;
-                const int k = j - i * inner;
-                drow[j] = srow[idx_in[i] * (int64_t)inner + k];
-            }
-        }
+    // Element gather (an in-channel list is present, or the layout rules out 16-byte moves).
+    const bool st4 = bases_vec_ok && (it.flags & 2);
+    if (idx_out) {
+        if (idx_in) gather_words<true, true>(it, src, dst, idx_out, idx_in, st4);
+        else gather_words<true, false>(it, src, dst, idx_out, idx_in, st4);
+    } else {
+        if (idx_in) gather_words<false, true>(it, src, dst, idx_out, idx_in, st4);
+        else gather_words<false, false>(it, src, dst, idx_out, idx_in, st4);
     }
 }
 
@@ -112,19 +171,12 @@ extern "C" int64_t spice_gather_plan(const spice_gather_desc *tensors, int32_t n
         if (d.dst_rows == 0 || row_len == 0) continue;
         const bool vec = d.idx_in_off < 0 && (row_len % 4 == 0) && (d.src_off % 4 == 0) &&
                          (d.dst_off % 4 == 0);
-        // lanes per row: every lane should own at least four (vector) copies of its row
-        const int64_t units = (vec ? row_len / 4 : row_len) / 4;
-        int L = kWave;
-        while (L > 1 && L > units) L >>= 1;
-        const int64_t groups = kGatherThreads / L;
-        // rows per item: whole lane-group passes on the indexed path; any count on the flat
-        // whole-row path, which walks the item's destination as one contiguous range
-        const int64_t unit = vec ? 1 : groups;
+        // rows per item: the kernel walks an item's destination as one contiguous range, so any
+        // row count will do; small items keep many workgroups in flight
         int64_t rpi = target / row_len;
         if (rpi < 1) rpi = 1;
-        rpi = ceil_div(rpi, unit) * unit;
         const int64_t n_it = ceil_div(d.dst_rows, rpi);
-        rpi = ceil_div(ceil_div(d.dst_rows, n_it), unit) * unit;
+        rpi = ceil_div(d.dst_rows, n_it);
         for (int64_t r0 = 0; r0 < d.dst_rows; r0 += rpi, ++n) {
             if (items == nullptr || n >= capacity) continue;
             spice_gather_item &it = items[n];
@@ -137,8 +189,8 @@ extern "C" int64_t spice_gather_plan(const spice_gather_desc *tensors, int32_t n
             it.dst_cols = (int32_t)d.dst_cols;
             it.src_cols = (int32_t)d.src_cols;
             it.inner = (int32_t)d.inner;
-            it.lanes = L;
-            it.flags = vec ? 1 : 0;
+            it.lanes = 0;
+            it.flags = (vec ? 1 : 0) | (((d.dst_off + r0 * row_len) % 4 == 0) ? 2 : 0);
             it.pad_ = 0;
         }
     }

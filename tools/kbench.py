@@ -103,6 +103,21 @@ def main():
                 fns = [lambda w=w, d=d: gplan.run(w.data_ptr(), d.data_ptr(), idx_t.data_ptr()) for w, d in zip(ws, dsts)]
                 report(f"{label} ({gplan.n_items} items)", timed(fns, args.iters), gplan.algorithmic_bytes())
                 del dsts
+            # both lists, as in a whole-model pruning step: every second out-channel AND in-channel
+            specs, idx, dpos, ipos = [], [], 0, 0
+            for (o, i, kh, kw), off in zip(shapes, offs):
+                ko = np.arange(0, o, 2, dtype=np.int64)
+                ki = np.arange(0, i, 2, dtype=np.int64) if i > 3 else np.arange(i, dtype=np.int64)
+                specs.append(ops.GatherSpec(off, dpos, ipos, ipos + len(ko), len(ko), len(ki), i, kh * kw))
+                idx += [ko, ki]
+                ipos += len(ko) + len(ki)
+                dpos += (len(ko) * len(ki) * kh * kw + 3) // 4 * 4
+            gplan = ops.GatherPlan(specs, dev)
+            idx_t = torch.from_numpy(np.concatenate(idx)).to(dev)
+            dsts = [torch.empty(dpos, device=dev) for _ in range(copies)]
+            fns = [lambda w=w, d=d: gplan.run(w.data_ptr(), d.data_ptr(), idx_t.data_ptr()) for w, d in zip(ws, dsts)]
+            report(f"gather_out50_in50 ({gplan.n_items} items)", timed(fns, args.iters), gplan.algorithmic_bytes())
+            del dsts
         del ws, gs
 
     if want("kdlite") or want("kdlite_grad"):

@@ -120,6 +120,9 @@ class FlatGradBuckets:
 
     def __init__(self, params, bucket_bytes: int = 32 << 20, align: int = 64):
         self.rank, self.world = world()
+        # set True around every backward of an optimisation step except the last one (gradient
+        # accumulation over chunks): buffers are exchanged only once the last backward fills them
+        self.hold = False
         ps = [p for p in params if p.requires_grad]
         ps.reverse()
         self.buckets: List[dict] = []
@@ -158,6 +161,8 @@ class FlatGradBuckets:
 
     def _make_hook(self, bi):
         def hook(_param):
+            if self.hold:  # an earlier backward of an accumulation step: more gradient is to come
+                return
             b = self.buckets[bi]
             b["pending"] -= 1
             if b["pending"] == 0:
@@ -178,6 +183,7 @@ class FlatGradBuckets:
             b["work"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def zero_grad(self) -> None:
+        self.hold = False
         for b in self.buckets:
             b["flat"].zero_()
             b["pending"], b["work"], b["launched"] = len(b["params"]), None, False

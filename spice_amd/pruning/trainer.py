@@ -152,6 +152,8 @@ class PruningTrainer:
                     if hi <= lo:
                         continue
                     loss = criterion(model(images[lo:hi]), masks[lo:hi]) / chunks
+                    if self._grad_buckets is not None:
+                        self._grad_buckets.hold = i < chunks - 1
                     loss.backward()
                     sums[0] += loss.detach()
             else:

@@ -133,6 +133,22 @@ def _grad_worker(rank, world, port, out_dir):
         if it == 0:
             grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.requires_grad}
         opt.step()
+    # gradient accumulation: two backward passes per step, exchange only after the second
+    net.eval()
+    buckets.zero_grad()
+    mid = (lo + hi) // 2 if hi - lo > 1 else hi
+    parts = [(lo, mid), (mid, hi)] if mid < hi else [(lo, hi)]
+    for k, (a, b) in enumerate(parts):
+        buckets.hold = k < len(parts) - 1
+        (torch.nn.functional.cross_entropy(net(xs[a:b]), ys[a:b], reduction="sum") / (12 * 12 * 4 / world)).backward()
+    buckets.finish()
+    acc_grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.requires_grad}
+    buckets.zero_grad()
+    (torch.nn.functional.cross_entropy(net(xs[lo:hi]), ys[lo:hi], reduction="sum") / (12 * 12 * 4 / world)).backward()
+    buckets.finish()
+    one_grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.requires_grad}
+    acc_err = max(float((acc_grads[n] - one_grads[n]).abs().max() / (one_grads[n].abs().max() + 1e-12)) for n in one_grads)
+    net.train()
     sdist.average_buffers_(net)
     # loaders: the training split is dealt to the ranks without overlap, validation by stride
     h = PruningDataHandler(data_root=os.path.join(out_dir, "nodata"), batch_size=2, seed=3, num_classes=4,
@@ -141,7 +157,7 @@ def _grad_worker(rank, world, port, out_dir):
     train_ids = [int(i) for i in train.sampler] if world > 1 else list(range(10))
     val_ids = list(val.dataset.indices) if world > 1 else list(range(10))
     cal_first = next(iter(h.get_calibration_dataloader()))[1][0, 0, :4].tolist()
-    np.savez(os.path.join(out_dir, f"grad_rank{rank}_of{world}.npz"), n_buckets=n_buckets,
+    np.savez(os.path.join(out_dir, f"grad_rank{rank}_of{world}.npz"), n_buckets=n_buckets, acc_err=acc_err,
              train_ids=np.array(train_ids), val_ids=np.array(val_ids), cal_first=np.array(cal_first),
              **{f"g/{k}": v.numpy() for k, v in grads.items()},
              **{f"p/{k}": v.detach().numpy() for k, v in net.named_parameters()},
@@ -159,6 +175,7 @@ def test_gradient_buckets_average_over_ranks(tmp_path):
     mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     two = [np.load(os.path.join(tmp_path, f"grad_rank{r}_of2.npz")) for r in range(2)]
     assert int(two[0]["n_buckets"]) > 1
+    assert float(two[0]["acc_err"]) < 1e-5 and float(two[1]["acc_err"]) < 1e-5 and float(one["acc_err"]) < 1e-5
     keys = [k for k in one.files if k.startswith("g/")]
     assert keys and "g/pw.bias" not in keys
     for k in keys:

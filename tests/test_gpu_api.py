@@ -273,3 +273,18 @@ def test_two_rank_sharded_evaluation(dev, tmp_path):
         got = json.load(open(tmp_path / f"eval_rank{r}_of2.json"))
         assert got == ref
     assert 0.0 <= ref["miou"] <= 1.0 and len(ref["per_class_iou"]) == 6
+
+
+def test_cli_run_prints_summary_and_writes_run_directory(dev, tmp_path, capsys):
+    """`python -m pruning.cli --model M --strategy S --ratio R ...` end to end at the reference's
+    default geometry (5 classes, 576x576), one step, one epoch each."""
+    from spice_amd.pruning import cli
+    cli.main(["--model", "FPN_resnet", "--strategy", "magnitude", "--pruning-ratio", "0.3", "--steps", "1",
+              "--fine-tune-epochs", "1", "--final-fine-tune-epochs", "1", "--batch-size", "4",
+              "--output-dir", str(tmp_path), "--data-root", str(tmp_path / "nodata"), "--seed", "3"])
+    out = capsys.readouterr().out
+    assert "PRUNING COMPLETE" in out and "Model: FPN_resnet" in out and "Strategy: magnitude" in out
+    run = tmp_path / "FPN_resnet_magnitude_0.30"
+    assert (run / "final_model.pth").exists() and (run / "metrics.json").exists()
+    assert (run / "intermediate" / "FPN_resnet_step_1_of_1.pth").exists()
+    assert "Pruning Ratio: 0.3" in (run / "model_info.txt").read_text()

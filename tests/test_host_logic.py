@@ -172,3 +172,14 @@ def test_partition_by_cost_properties():
         loads = [sum(costs[i] for i in p) for p in parts]
         assert max(loads) - min(loads) <= max(costs)
     assert sdist.partition_by_cost(costs, 2) == sdist.partition_by_cost(costs, 2)
+
+
+def test_cli_exits_with_status_one_on_failure(tmp_path, capsys):
+    """Any exception ends the command with exit status 1 (pruning/cli.py:43-48); here the
+    failure is the refusal to run on a CPU device."""
+    from spice_amd.pruning import cli
+    with pytest.raises(SystemExit) as e:
+        cli.main(["--model", "UNET_resnet", "--strategy", "magnitude", "--ratio", "0.3", "--device", "cpu",
+                  "--output-dir", str(tmp_path), "--data-root", str(tmp_path / "nodata")])
+    assert e.value.code == 1
+    assert "PRUNING COMPLETE" not in capsys.readouterr().out

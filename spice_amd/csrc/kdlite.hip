@@ -104,23 +104,55 @@ __device__ __forceinline__ void load_labels(const long long *p, long long (&v)[V
     }
 }
 
-// 3x3 dilate != erode on the label image (borders use in-bounds neighbours only).
-__device__ __forceinline__ bool label_boundary(const long long *img, long long pix, int H, int W) {
-    const int y = (int)(pix / W);
-    const int x = (int)(pix - (long long)y * W);
-    long long mn = img[pix], mx = mn;
-    for (int dy = -1; dy <= 1; ++dy) {
-        const int yy = y + dy;
-        if (yy < 0 || yy >= H) continue;
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int xx = x + dx;
-            if (xx < 0 || xx >= W) continue;
-            const long long v = img[(long long)yy * W + xx];
-            mn = v < mn ? v : mn;
-            mx = v > mx ? v : mx;
+// 3x3 dilate != erode on the label image (borders use in-bounds neighbours only) for the VEC
+// consecutive pixels that start at offset r of one image.  Out-of-image neighbours are replaced
+// by clamped coordinates: the clamped pixel is itself inside the 3x3 window, so minimum and
+// maximum do not change.  When the group lies in one image row its windows share columns: three
+// rows of VEC + 2 labels are read once and reduced column-wise first.
+template <int VEC>
+__device__ __forceinline__ void label_boundary_group(const long long *__restrict__ img, int r, int H, int W,
+                                                     bool (&edge)[VEC]) {
+    const int y = r / W;
+    const int x = r - y * W;
+    if (VEC > 1 && x + VEC - 1 < W) {
+        long long cmn[VEC + 2], cmx[VEC + 2];
+        const long long *rows[3] = {img + (long long)max(y - 1, 0) * W, img + (long long)y * W,
+                                    img + (long long)min(y + 1, H - 1) * W};
+#pragma unroll
+        for (int j = 0; j < VEC + 2; ++j) {
+            const int xx = min(max(x - 1 + j, 0), W - 1);
+            const long long a = rows[0][xx], b = rows[1][xx], c = rows[2][xx];
+            cmn[j] = a < b ? (a < c ? a : c) : (b < c ? b : c);
+            cmx[j] = a > b ? (a > c ? a : c) : (b > c ? b : c);
         }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            long long mn = cmn[e] < cmn[e + 1] ? cmn[e] : cmn[e + 1];
+            long long mx = cmx[e] > cmx[e + 1] ? cmx[e] : cmx[e + 1];
+            mn = cmn[e + 2] < mn ? cmn[e + 2] : mn;
+            mx = cmx[e + 2] > mx ? cmx[e + 2] : mx;
+            edge[e] = mn != mx;
+        }
+        return;
     }
-    return mn != mx;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int pe = r + e;
+        const int ye = pe / W;
+        const int xe = pe - ye * W;
+        long long mn = img[pe], mx = mn;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const long long *row = img + (long long)min(max(ye + dy, 0), H - 1) * W;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const long long v = row[min(max(xe + dx, 0), W - 1)];
+                mn = v < mn ? v : mn;
+                mx = v > mx ? v : mx;
+            }
+        }
+        edge[e] = mn != mx;
+    }
 }
 
 // Sum `NQ` per-thread doubles over the workgroup; thread 0..NQ-1 of wave 0 end up holding the
@@ -211,12 +243,16 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_prepass_kernel(KdArgs a) {
             }
         }
         float nv = 0.f, ws = 0.f, nb = 0.f, cs = 0.f;
+        bool edge[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) edge[e] = false;
+        if (use_b) label_boundary_group<VEC>(lab_img, r, a.H, a.W, edge);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const bool valid = id[e] != -1;
             if (valid) nv += 1.f;
             if (id[e] >= 0) ws += a.class_w ? a.class_w[id[e]] : 1.f;
-            if (use_b && valid && label_boundary(lab_img, r + e, a.H, a.W)) nb += 1.f;
+            if (use_b && valid && edge[e]) nb += 1.f;
             if (use_c && valid) cs += 1.f / zt1[e];
         }
         acc[0] += nv;
@@ -471,6 +507,10 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
         }
 
         float wy[VEC], wkd[VEC];
+        bool edge[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) edge[e] = false;
+        if (use_b) label_boundary_group<VEC>(lab_img, r, a.H, a.W, edge);
         float p_kl = 0.f, p_nv = 0.f, p_ce = 0.f, p_w = 0.f, p_bk = 0.f, p_nb = 0.f, p_ck = 0.f, p_cs = 0.f;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -490,7 +530,7 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
                 p_w += wy[e];
             }
             if (use_b) {
-                if (valid && label_boundary(lab_img, r + e, a.H, a.W)) {
+                if (valid && edge[e]) {
                     p_bk += kl;
                     p_nb += 1.f;
                     wk += (a.bw - 1.0f) * inv_nb;

@@ -233,6 +233,15 @@ __global__ __launch_bounds__(kConfThreads) void argmax_confusion_kernel(
         const int64_t n = q / per_img;
         const int64_t r = (q - n * per_img) * VEC;
         const T *base = logits + n * C * HW + r;
+        // labels first, reduced to a row offset at once (-1 = skip): consumed here, so their loads
+        // are issued with the first class plane instead of one by one behind the class loop
+        const long long *tp = target + n * HW + r;
+        int trow[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const long long t = tp[e];
+            trow[e] = (t >= 0 && t < C) ? (int)t * C : -1;
+        }
         float best[VEC];
         int arg[VEC];
         {
@@ -262,11 +271,9 @@ __global__ __launch_bounds__(kConfThreads) void argmax_confusion_kernel(
 #pragma unroll
             for (int e = 0; e < VEC; ++e) argmax_step(to_f32<T>(x0.v[e]), c, best[e], arg[e]);
         }
-        const long long *tp = target + n * HW + r;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            const long long t = tp[e];
-            if (t >= 0 && t < C) atomicAdd(&hist[(int)t * C + arg[e]], 1u);
+            if (trow[e] >= 0) atomicAdd(&hist[trow[e] + arg[e]], 1u);
         }
     }
     __syncthreads();

@@ -89,10 +89,10 @@ __global__ __launch_bounds__(kConfThreads) void confusion_hist_kernel(
         const I64x2 *t2 = reinterpret_cast<const I64x2 *>(target);
         int64_t i = gtid;
         for (; i + 3 * gthreads < n2; i += 4 * gthreads) {
-            const I64x2 ta = t2[i], tb = t2[i + gthreads], tc = t2[i + 2 * gthreads],
-                        td = t2[i + 3 * gthreads];
-            const I64x2 pa = p2[i], pb = p2[i + gthreads], pc = p2[i + 2 * gthreads],
-                        pd = p2[i + 3 * gthreads];
+            const I64x2 ta = ld_stream16(t2 + (i)), tb = ld_stream16(t2 + (i + gthreads)), tc = ld_stream16(t2 + (i + 2 * gthreads)),
+                        td = ld_stream16(t2 + (i + 3 * gthreads));
+            const I64x2 pa = ld_stream16(p2 + (i)), pb = ld_stream16(p2 + (i + gthreads)), pc = ld_stream16(p2 + (i + 2 * gthreads)),
+                        pd = ld_stream16(p2 + (i + 3 * gthreads));
             conf_count(hist, ta.x, pa.x, C, bad);
             conf_count(hist, ta.y, pa.y, C, bad);
             conf_count(hist, tb.x, pb.x, C, bad);
@@ -103,8 +103,8 @@ __global__ __launch_bounds__(kConfThreads) void confusion_hist_kernel(
             conf_count(hist, td.y, pd.y, C, bad);
         }
         for (; i < n2; i += gthreads) {
-            const I64x2 ta = t2[i];
-            const I64x2 pa = p2[i];
+            const I64x2 ta = ld_stream16(t2 + (i));
+            const I64x2 pa = ld_stream16(p2 + (i));
             conf_count(hist, ta.x, pa.x, C, bad);
             conf_count(hist, ta.y, pa.y, C, bad);
         }
@@ -216,6 +216,16 @@ struct alignas(sizeof(T) * VEC) Pack {
     T v[VEC];
 };
 
+// One pack of class-plane values; streamed (read once) when it is a 16-byte pack.
+template <typename T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> load_pack(const T *p) {
+    if constexpr (sizeof(Pack<T, VEC>) == 16) {
+        return ld_stream16(reinterpret_cast<const Pack<T, VEC> *>(p));
+    } else {
+        return *reinterpret_cast<const Pack<T, VEC> *>(p);
+    }
+}
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(kConfThreads) void argmax_confusion_kernel(
     const T *__restrict__ logits, const long long *__restrict__ target, int64_t N, int64_t HW, int C,
@@ -245,7 +255,7 @@ __global__ __launch_bounds__(kConfThreads) void argmax_confusion_kernel(
         float best[VEC];
         int arg[VEC];
         {
-            const Pack<T, VEC> x = *reinterpret_cast<const Pack<T, VEC> *>(base);
+            const Pack<T, VEC> x = load_pack<T, VEC>(base);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 best[e] = to_f32<T>(x.v[e]);
@@ -254,10 +264,10 @@ __global__ __launch_bounds__(kConfThreads) void argmax_confusion_kernel(
         }
         int c = 1;
         for (; c + 3 < C; c += 4) {
-            const Pack<T, VEC> x0 = *reinterpret_cast<const Pack<T, VEC> *>(base + (int64_t)c * HW);
-            const Pack<T, VEC> x1 = *reinterpret_cast<const Pack<T, VEC> *>(base + (int64_t)(c + 1) * HW);
-            const Pack<T, VEC> x2 = *reinterpret_cast<const Pack<T, VEC> *>(base + (int64_t)(c + 2) * HW);
-            const Pack<T, VEC> x3 = *reinterpret_cast<const Pack<T, VEC> *>(base + (int64_t)(c + 3) * HW);
+            const Pack<T, VEC> x0 = load_pack<T, VEC>(base + (int64_t)c * HW);
+            const Pack<T, VEC> x1 = load_pack<T, VEC>(base + (int64_t)(c + 1) * HW);
+            const Pack<T, VEC> x2 = load_pack<T, VEC>(base + (int64_t)(c + 2) * HW);
+            const Pack<T, VEC> x3 = load_pack<T, VEC>(base + (int64_t)(c + 3) * HW);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 argmax_step(to_f32<T>(x0.v[e]), c, best[e], arg[e]);
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(kConfThreads) void argmax_confusion_kernel(
             }
         }
         for (; c < C; ++c) {
-            const Pack<T, VEC> x0 = *reinterpret_cast<const Pack<T, VEC> *>(base + (int64_t)c * HW);
+            const Pack<T, VEC> x0 = load_pack<T, VEC>(base + (int64_t)c * HW);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) argmax_step(to_f32<T>(x0.v[e]), c, best[e], arg[e]);
         }

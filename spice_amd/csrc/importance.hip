@@ -59,22 +59,22 @@ __global__ __launch_bounds__(kImpThreads) void importance_rows_kernel(
             for (; j + 7 * L < K4; j += 8 * L) {
                 float4 x[8], y[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = w4[j + u * L];
+                for (int u = 0; u < 8; ++u) x[u] = ld_stream16(w4 + (j + u * L));
 #pragma unroll
-                for (int u = 0; u < 8; ++u) y[u] = (MODE == SPICE_IMP_TAYLOR) ? g4[j + u * L] : x[u];
+                for (int u = 0; u < 8; ++u) y[u] = (MODE == SPICE_IMP_TAYLOR) ? ld_stream16(g4 + (j + u * L)) : x[u];
                 a0 += imp_term4<MODE>(x[0], y[0]) + imp_term4<MODE>(x[4], y[4]);
                 a1 += imp_term4<MODE>(x[1], y[1]) + imp_term4<MODE>(x[5], y[5]);
                 a2 += imp_term4<MODE>(x[2], y[2]) + imp_term4<MODE>(x[6], y[6]);
                 a3 += imp_term4<MODE>(x[3], y[3]) + imp_term4<MODE>(x[7], y[7]);
             }
             for (; j + 3 * L < K4; j += 4 * L) {
-                const float4 x0 = w4[j], x1 = w4[j + L], x2 = w4[j + 2 * L], x3 = w4[j + 3 * L];
+                const float4 x0 = ld_stream16(w4 + (j)), x1 = ld_stream16(w4 + (j + L)), x2 = ld_stream16(w4 + (j + 2 * L)), x3 = ld_stream16(w4 + (j + 3 * L));
                 float4 y0 = x0, y1 = x1, y2 = x2, y3 = x3;
                 if (MODE == SPICE_IMP_TAYLOR) {
-                    y0 = g4[j];
-                    y1 = g4[j + L];
-                    y2 = g4[j + 2 * L];
-                    y3 = g4[j + 3 * L];
+                    y0 = ld_stream16(g4 + (j));
+                    y1 = ld_stream16(g4 + (j + L));
+                    y2 = ld_stream16(g4 + (j + 2 * L));
+                    y3 = ld_stream16(g4 + (j + 3 * L));
                 }
                 a0 += imp_term4<MODE>(x0, y0);
                 a1 += imp_term4<MODE>(x1, y1);
@@ -82,9 +82,9 @@ __global__ __launch_bounds__(kImpThreads) void importance_rows_kernel(
                 a3 += imp_term4<MODE>(x3, y3);
             }
             for (; j < K4; j += L) {
-                const float4 x0 = w4[j];
+                const float4 x0 = ld_stream16(w4 + (j));
                 float4 y0 = x0;
-                if (MODE == SPICE_IMP_TAYLOR) y0 = g4[j];
+                if (MODE == SPICE_IMP_TAYLOR) y0 = ld_stream16(g4 + (j));
                 a0 += imp_term4<MODE>(x0, y0);
             }
         } else {

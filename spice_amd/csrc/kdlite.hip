@@ -81,6 +81,22 @@ __device__ __forceinline__ void load_vec(const float *p, float (&v)[VEC]) {
     }
 }
 
+// Streaming variant: the logits are read once and never again, so they need not displace anything
+// in the caches (non-temporal load policy).
+template <int VEC>
+__device__ __forceinline__ void load_vec_nt(const float *p, float (&v)[VEC]) {
+    if (VEC == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 x = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
+        v[0] = x.x;
+        v[1 % VEC] = x.y;
+        v[2 % VEC] = x.z;
+        v[3 % VEC] = x.w;
+    } else {
+        v[0] = __builtin_nontemporal_load(p);
+    }
+}
+
 template <int VEC>
 __device__ __forceinline__ void store_vec(float *p, const float (&v)[VEC]) {
     if (VEC == 4) {
@@ -282,8 +298,8 @@ __device__ __forceinline__ void kd_fold(PixStats<VEC> &st, const float *__restri
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int cc = FULL ? c0 + u : min(c0 + u, C - 1);
-        load_vec<VEC>(s_img + (long long)cc * HW + r, sv[u]);
-        load_vec<VEC>(t_img + (long long)cc * HW + r, tv[u]);
+        load_vec_nt<VEC>(s_img + (long long)cc * HW + r, sv[u]);
+        load_vec_nt<VEC>(t_img + (long long)cc * HW + r, tv[u]);
     }
     if (STAGE) {
 #pragma unroll

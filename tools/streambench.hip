@@ -79,5 +79,24 @@ int main() {
         for (auto b : bufs) hipFree(b);
         hipFree(out);
     }
+    // finer sweep at the KD-Lite size (369 MB): workgroups x unroll x load policy
+    {
+        const size_t bytes = 352 * MB;
+        const int nc = 3;
+        std::vector<float4*> bufs(nc);
+        for (auto& b : bufs) { if (hipMalloc(&b, bytes) != hipSuccess) { printf("alloc failed\n"); return 1; } hipMemset(b, 1, bytes); }
+        float* out; hipMalloc(&out, 65536 * 4); hipMemset(out, 0, 65536 * 4);
+        const size_t n4 = bytes / 16;
+        for (int blocks : {512, 1024, 2048, 4096, 8192, 16384}) {
+            float a = time_us([&](int i) { hipLaunchKernelGGL((read_sum<8, false>), dim3(blocks), dim3(256), 0, 0, bufs[i % nc], n4, out); }, 15);
+            float b = time_us([&](int i) { hipLaunchKernelGGL((read_sum<8, true>), dim3(blocks), dim3(256), 0, 0, bufs[i % nc], n4, out); }, 15);
+            float c = time_us([&](int i) { hipLaunchKernelGGL((read_sum<16, false>), dim3(blocks), dim3(256), 0, 0, bufs[i % nc], n4, out); }, 15);
+            float d = time_us([&](int i) { hipLaunchKernelGGL((read_sum<16, true>), dim3(blocks), dim3(256), 0, 0, bufs[i % nc], n4, out); }, 15);
+            printf("352 MB blocks %5d: u8 %6.1f us (%4.2f TB/s) | u8 nt %6.1f (%4.2f) | u16 %6.1f (%4.2f) | u16 nt %6.1f (%4.2f)\n",
+                   blocks, a, bytes / a / 1e6, b, bytes / b / 1e6, c, bytes / c / 1e6, d, bytes / d / 1e6);
+        }
+        for (auto b : bufs) hipFree(b);
+        hipFree(out);
+    }
     return 0;
 }

@@ -63,6 +63,12 @@ __device__ __forceinline__ T ld_stream16(const T *p) {
     return __builtin_bit_cast(T, x);
 }
 
+template <typename T>
+__device__ __forceinline__ void st_stream16(T *p, const T &v) {
+    static_assert(sizeof(T) == 16, "st_stream16 moves exactly 16 bytes");
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), reinterpret_cast<u32x4_t *>(p));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);

@@ -127,14 +127,14 @@ __global__ __launch_bounds__(kGatherThreads) void gather_kernel(
             }
             uint4 v[kU];
 #pragma unroll
-            for (int u = 0; u < kU; ++u) v[u] = src4[so[u] * stride4 + col[u]];
+            for (int u = 0; u < kU; ++u) v[u] = ld_stream16(src4 + (so[u] * stride4 + col[u]));
 #pragma unroll
-            for (int u = 0; u < kU; ++u) dst4[f0 + u * kGatherThreads] = v[u];
+            for (int u = 0; u < kU; ++u) st_stream16(dst4 + (f0 + u * kGatherThreads), v[u]);
         }
         for (; f0 < total4; f0 += kGatherThreads) {
             const int row = f0 / n4;
             const long long so = idx_out ? idx_out[row] : (long long)(it.row0 + row);
-            dst4[f0] = src4[so * stride4 + (f0 - row * n4)];
+            st_stream16(dst4 + f0, ld_stream16(src4 + (so * stride4 + (f0 - row * n4))));
         }
         return;
     }

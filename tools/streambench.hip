@@ -1,5 +1,5 @@
 // Ceiling probe: how fast can gfx950 stream-read N bytes with a trivial reduction, as a function
-// of size, blocks and unroll?  Build: hipcc --offload-arch=gfx950 -O3 tools/streambench.hip -o build/streambench
+// of size, blocks and unroll?  Build: hipcc -w --offload-arch=gfx950 -O3 tools/streambench.hip -o tools/streambench.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

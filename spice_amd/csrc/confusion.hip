@@ -8,6 +8,8 @@
 // independent of scheduling.
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <hip/hip_fp16.h>
 
 namespace spice {
@@ -45,7 +47,9 @@ static inline int argmax_blocks(int64_t n_threads_needed) {
 
 static inline int conf_blocks(int64_t n_pixels) {
     // one workgroup per ~8K pixels (one per CU for an 8x512x512 batch), at most kConfMaxBlocks
-    int64_t b = ceil_div(n_pixels, (int64_t)kConfThreads * 16);
+    const char *e = getenv("SPICE_CONF_PIXELS_PER_BLOCK");  // tuning knob (host side only)
+    const long v = e ? atol(e) : 0;
+    int64_t b = ceil_div(n_pixels, v >= 512 ? (int64_t)v : (int64_t)kConfThreads * 16);
     if (b < 1) b = 1;
     if (b > kConfMaxBlocks) b = kConfMaxBlocks;
     return (int)b;

@@ -367,3 +367,48 @@ def test_selected_indices_from_device_scores_match_oracle(dev):
             mine = osel.select_local(got, n_pruned)
             theirs = osel.select_local(oi.magnitude_rows_f64(w, 2), n_pruned)
             np.testing.assert_array_equal(mine, theirs)
+
+
+def test_gather_unaligned_offsets_and_odd_rows(dev):
+    """Layouts that rule out 16-byte moves: destinations and sources at offsets that are not a
+    multiple of four words, rows of odd length, one-row and one-column tensors, identity row
+    lists with a column list, and items larger than one work item."""
+    rng = np.random.default_rng(5)
+    # (rows, cols, inner, keep_out?, keep_in?)
+    tensors = [(7, 5, 9, True, True), (33, 1, 1, True, False), (1, 40, 1, False, True), (19, 3, 49, True, False),
+               (300, 17, 1, True, True), (4, 4, 4, False, False), (65, 130, 9, False, True), (2048, 3, 1, True, False)]
+    srcs, specs, idx_parts, refs = [], [], [], []
+    spos, dpos, ipos = 1, 3, 0  # deliberately unaligned starts
+    for rows, cols, inner, use_out, use_in in tensors:
+        w = rng.standard_normal((rows, cols, inner)).astype(np.float32)
+        ko = np.sort(rng.choice(rows, max(1, rows * 2 // 3), replace=False)).astype(np.int64) if use_out else None
+        ki = np.sort(rng.choice(cols, max(1, cols // 2), replace=False)).astype(np.int64) if use_in else None
+        ref = w[ko] if ko is not None else w
+        ref = ref[:, ki] if ki is not None else ref
+        o_off = i_off = -1
+        if ko is not None:
+            o_off, ipos = ipos, ipos + len(ko)
+            idx_parts.append(ko)
+        if ki is not None:
+            i_off, ipos = ipos, ipos + len(ki)
+            idx_parts.append(ki)
+        specs.append(ops.GatherSpec(spos, dpos, o_off, i_off, ref.shape[0], ref.shape[1], cols, inner))
+        srcs.append((spos, w))
+        refs.append(ref)
+        spos += w.size + int(rng.integers(0, 3))
+        dpos += ref.size + int(rng.integers(0, 3))
+    src = np.zeros(spos + 8, dtype=np.float32)
+    for off, w in srcs:
+        src[off: off + w.size] = w.reshape(-1)
+    plan = ops.GatherPlan(specs, dev)
+    guard = np.float32(-7.25)
+    dst = torch.full((dpos + 8,), float(guard), dtype=torch.float32, device=dev)
+    idx = torch.from_numpy(np.concatenate(idx_parts)).to(dev)
+    plan.run(torch.from_numpy(src).to(dev).data_ptr(), dst.data_ptr(), idx.data_ptr())
+    out = dst.cpu().numpy()
+    written = np.zeros(out.shape, dtype=bool)
+    for spec, ref in zip(specs, refs):
+        got = out[spec.dst_off: spec.dst_off + ref.size].reshape(ref.shape)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (spec, ref.shape)
+        written[spec.dst_off: spec.dst_off + ref.size] = True
+    assert (out[~written] == guard).all()  # nothing outside the destinations was touched

@@ -190,6 +190,27 @@ def test_kdlite_config3_size(dev, variant):
     assert ops.kdlite_bad_label_count(dev) == 0
 
 
+@pytest.mark.parametrize("c,hw,variant", [(24, (20, 28), "default"), (25, (20, 28), "default"), (40, (9, 13), "boundary_conf"),
+                                          (2, (7, 5), "default"), (24, (6, 10), "boundary_conf"), (1, (8, 8), "default")])
+def test_kdlite_gradient_both_sides_of_the_lds_limit(dev, c, hw, variant):
+    """The gradient pass parks the logits in LDS up to 24 classes and re-reads them above that:
+    both variants against the op-sequence oracle, aligned and odd geometries, 1 and 2 classes."""
+    h, w = hw
+    g = torch.Generator().manual_seed(100 + c)
+    s = 3.0 * torch.randn(2, c, h, w, generator=g)
+    t = s + torch.randn(2, c, h, w, generator=g)
+    lab = torch.randint(0, c, (2, h, w), generator=g)
+    lab[torch.rand(2, h, w, generator=g) < 0.1] = 255
+    kw = dict(temperature=3.0, alpha=0.6)
+    if variant != "default":
+        kw.update(boundary_weight=2.5, confidence_weight=True)
+    out3, grad, _ = ops.kdlite_forward(s.to(dev), t.to(dev), lab.to(dev), want_grad=True, **kw)
+    ref, g_ref = ok.kdlite_loss_and_grad(s, t, lab, num_classes=c, **kw)
+    for k, key in enumerate(("total", "ce", "kd")):
+        assert abs(out3[k].item() - ref[key].item()) <= REL * abs(ref[key].item()) + 1e-7, (key, out3[k].item(), ref[key].item())
+    assert (grad.cpu() - g_ref).abs().max().item() <= REL * g_ref.abs().max().item() + 1e-9
+
+
 def test_kdlite_coefficients_and_upstream(dev):
     kw, c = _kd_kwargs("c21_default")
     s = torch.from_numpy(KD["c21_default/student"]).to(dev)

@@ -288,3 +288,42 @@ def test_cli_run_prints_summary_and_writes_run_directory(dev, tmp_path, capsys):
     assert (run / "final_model.pth").exists() and (run / "metrics.json").exists()
     assert (run / "intermediate" / "FPN_resnet_step_1_of_1.pth").exists()
     assert "Pruning Ratio: 0.3" in (run / "model_info.txt").read_text()
+
+
+def test_integration_stub_runs_as_documented(dev):
+    """The ctypes binding shown in INTEGRATION.md (raw library, no spice_amd.ops): the reference's
+    update_confusion_matrix body replaced by one spice_confusion_update call."""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                   "spice_amd", "lib", "libspice_amd.so"))
+    lib.spice_confusion_workspace_bytes.restype = ctypes.c_size_t
+    lib.spice_confusion_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
+    lib.spice_confusion_update.restype = ctypes.c_int32
+    lib.spice_confusion_update.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    ws_cache = {}
+
+    def update_confusion_matrix(conf, preds, target, num_classes):
+        p, t = preds.reshape(-1).contiguous(), target.reshape(-1).contiguous()
+        key = (conf.device.index, num_classes)
+        if key not in ws_cache:
+            n = lib.spice_confusion_workspace_bytes(p.numel(), num_classes)
+            ws_cache[key] = torch.zeros(n, dtype=torch.uint8, device=conf.device)
+        ws = ws_cache[key]
+        rc = lib.spice_confusion_update(p.data_ptr(), t.data_ptr(), p.numel(), num_classes, conf.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        if rc:
+            raise RuntimeError(f"spice_confusion_update failed: {rc}")
+
+    g = torch.Generator().manual_seed(9)
+    c = 19
+    conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
+    want = np.zeros((c, c), dtype=np.int64)
+    for _ in range(2):
+        t = torch.randint(0, c, (3, 50, 70), generator=g)
+        p = torch.randint(0, c, (3, 50, 70), generator=g)
+        t[torch.rand(3, 50, 70, generator=g) < 0.1] = 255
+        update_confusion_matrix(conf, p.to(dev), t.to(dev), c)
+        oc.update_confusion(want, p.numpy(), t.numpy(), c)
+    np.testing.assert_array_equal(conf.cpu().numpy(), want)
+    assert lib.spice_confusion_update(None, None, 5, c, None, None, 0, None) != 0  # argument errors are return codes

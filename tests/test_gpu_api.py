@@ -27,6 +27,13 @@ KD = load_golden("kdlite.npz")
 TY = load_golden("taylor.npz")
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available()
@@ -242,7 +249,7 @@ def test_two_rank_prune_and_finetune(dev, tmp_path):
     import sys
     env = dict(os.environ, SPICE_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(os.path.dirname(__file__), "ddp_prune_worker.py"), str(tmp_path)]
     done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
     assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
@@ -265,7 +272,7 @@ def test_two_rank_sharded_evaluation(dev, tmp_path):
     assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
     env = dict(os.environ, SPICE_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29534", worker, str(tmp_path)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), worker, str(tmp_path)],
                          env=env, capture_output=True, text=True, timeout=300)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
     ref = json.load(open(tmp_path / "eval_rank0_of1.json"))

@@ -84,8 +84,27 @@ def magnitude_cols_f64(weight: np.ndarray, p: int) -> np.ndarray:
     return np.swapaxes(w, 0, 1).reshape(weight.shape[1], -1).sum(axis=1)
 
 
-def group_magnitude(member_terms: Sequence[torch.Tensor]) -> torch.Tensor:
-    """Group reduction "mean" over the members' per-channel terms, then normalizer "mean"."""
+def group_magnitude(member_terms: Sequence[torch.Tensor], normalizer: str = "mean") -> torch.Tensor:
+    """Group reduction "mean" over the members' per-channel terms, then the normalizer:
+    "mean" (MagnitudeImportance's default) or "lamp" (LAMPImportance: every score divided by the
+    sum of all scores not smaller than it, i.e. a cumulative sum over the descending order)."""
+    stacked = torch.stack([t.float() for t in member_terms], dim=0)
+    imp = stacked.sum(dim=0) / len(member_terms)
+    if normalizer == "mean":
+        return imp / imp.mean()
+    if normalizer == "lamp":
+        order = torch.argsort(imp, descending=True, stable=True)
+        srt = imp[order]
+        scaled = srt / torch.cumsum(srt, dim=0)
+        out = torch.empty_like(scaled)
+        out[order] = scaled
+        return out
+    raise ValueError(normalizer)
+
+
+def group_taylor(member_terms: Sequence[torch.Tensor]) -> torch.Tensor:
+    """tp.importance.TaylorImportance with its defaults on the producers of a group: mean over
+    members of sum |w * dL/dw| per out-channel, divided by the mean over channels."""
     stacked = torch.stack([t.float() for t in member_terms], dim=0)
     imp = stacked.sum(dim=0) / len(member_terms)
     return imp / imp.mean()

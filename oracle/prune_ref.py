@@ -18,7 +18,7 @@ from . import importance as oi
 from . import selection as osel
 
 
-def group_importance(group, p: int) -> Optional[np.ndarray]:
+def group_importance(group, p: int, normalizer: str = "mean") -> Optional[np.ndarray]:
     terms = []
     for m in group.members:
         mod = m.module
@@ -35,7 +35,20 @@ def group_importance(group, p: int) -> Optional[np.ndarray]:
             terms.append(mod.weight.detach().abs().pow(p)[o: o + group.size])
     if not terms:
         return None
-    return oi.group_magnitude(terms).numpy()
+    return oi.group_magnitude(terms, normalizer).numpy()
+
+
+def group_taylor_importance(group) -> Optional[np.ndarray]:
+    """Per-channel first-order Taylor criterion of a group from the gradients on its producers."""
+    terms = []
+    for m in group.members:
+        mod = m.module
+        if m.kind in ("out", "dw"):
+            o = 0 if m.kind == "out" else m.offset()
+            terms.append(oi.taylor_rows(mod.weight, mod.weight.grad)[o: o + group.size])
+    if not terms:
+        return None
+    return oi.group_taylor(terms).numpy()
 
 
 def _slice_param(mod: nn.Module, attr: str, dim: int, keep: np.ndarray) -> None:

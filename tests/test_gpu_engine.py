@@ -108,3 +108,49 @@ def test_ratio_dict_min_channels_and_gradients(dev):
     assert gpu.encoder.layer1[0].conv2.out_channels == 64  # ratio 0 everywhere else
     with pytest.raises(IndexError):
         pruner.step()
+
+
+def test_lamp_taylor_and_random_criteria(dev):
+    """The criteria behind --strategy lamp / taylor / random (pruning/pruning_core.py:146-151) on
+    every group of a UNet-ResNet50: LAMP and first-order Taylor against the oracle, random for
+    its contract (one score per channel, reproducible under a seed)."""
+    base = _make("Unet", "resnet50", seed=4)
+    cpu = copy.deepcopy(base)
+    gpu = copy.deepcopy(base).to(dev)
+    x = torch.randn(2, 3, 64, 64)
+    y = torch.randint(0, 7, (2, 64, 64))
+    for m, xx, yy in ((cpu, x, y), (gpu, x.to(dev), y.to(dev))):
+        nn.functional.cross_entropy(m(xx), yy).backward()
+    g_groups = engine.MagnitudePruner(gpu, ignored_layers=_ignored(gpu)).prunable_groups()
+    c_groups = {g.root_name: g for g in build_groups(cpu) if not g.frozen}
+    lamp, taylor, rnd = engine.LAMPImportance(), engine.TaylorImportance(), engine.RandomImportance()
+    checked = 0
+    for g in g_groups:
+        ref_g = c_groups[g.root_name]
+        want = prune_ref.group_importance(ref_g, 2, "lamp")
+        got = lamp(g).numpy()
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-9)
+        assert (got > 0).all() and got.max() <= 1.0 + 1e-6   # the largest score is divided by itself
+        want_t = prune_ref.group_taylor_importance(ref_g)
+        if want_t is not None:
+            # forward/backward ran on different devices: gradients agree to ~1e-4, not to rounding
+            np.testing.assert_allclose(taylor(g).numpy(), want_t, rtol=5e-3, atol=1e-6)
+            checked += 1
+        torch.manual_seed(11)
+        a = rnd(g)
+        torch.manual_seed(11)
+        b = rnd(g)
+        assert a.shape == (g.size,) and torch.equal(a, b) and 0.0 <= float(a.min()) and float(a.max()) < 1.0
+    assert checked >= 10
+    # a pruner built on each criterion steps and keeps the model runnable
+    for imp in (lamp, taylor, rnd):
+        m = copy.deepcopy(gpu)
+        for p_src, p_dst in zip(gpu.parameters(), m.parameters()):
+            p_dst.grad = None if p_src.grad is None else p_src.grad.clone()
+        pr = engine.MagnitudePruner(m, importance=imp, pruning_ratio=0.3, iterative_steps=1,
+                                    ignored_layers=_ignored(m), global_pruning=True)
+        pr.step()
+        with torch.no_grad():
+            assert m(x.to(dev)).shape == (2, 7, 64, 64)
+        assert sum(p.numel() for p in m.parameters()) < sum(p.numel() for p in gpu.parameters())

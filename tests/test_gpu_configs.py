@@ -111,3 +111,36 @@ def test_config3_unet_efficientnet_taylor_quotas_then_ten_kd_steps(dev, tmp_path
         opt.step()
         totals.append(d["total"].item())
     assert totals[-1] < totals[0]  # ten steps on one batch must reduce its loss
+
+
+@pytest.mark.parametrize("model_name,strategy", [("DeepLabV3Plus_resnet", "taylor_weight"), ("FPN_efficientnet", "taylor_weight"),
+                                                 ("UNET_resnet", "lamp"), ("DeepLabV3Plus_efficientnet", "random")])
+def test_remaining_strategies_set_up_and_step(dev, tmp_path, model_name, strategy):
+    """--strategy taylor_weight (Taylor scores served to a global-threshold pruner through the
+    importance plug-in protocol, group-synchronised for these model names), lamp and random:
+    set-up through the orchestrator, two steps, the model stays runnable and shrinks as scheduled."""
+    cfg = PruningConfig(model_name=model_name, output_dir=str(tmp_path), data_root=str(tmp_path / "nodata"),
+                        num_classes=5, input_size=(64, 64), example_input_size=(1, 3, 64, 64), pruning_ratio=0.4,
+                        iterative_steps=2, pruning_strategy=strategy, device="cuda", batch_size=4,
+                        calibration_batches=2, use_wandb=False)
+    model = ModelFactory.load_pretrained_model(cfg).to(dev)
+    before = sum(p.numel() for p in model.parameters())
+    pruner, info = PruningOrchestrator(cfg).setup_importance_and_pruner(
+        model, torch.randn(1, 3, 64, 64, device=dev), ModelFactory.get_ignored_layers(model, cfg))
+    if strategy == "taylor_weight":
+        rep = info["sensitivity_report"]
+        assert rep["num_layers"] == sum(1 for m in model.modules() if isinstance(m, nn.Conv2d))
+        assert all(np.isfinite(s["mean_sensitivity"]) for s in rep["layer_stats"])
+    else:
+        assert info == {}
+    sizes = [before]
+    for _ in range(2):
+        pruner.step()
+        sizes.append(sum(p.numel() for p in model.parameters()))
+        with torch.no_grad():
+            assert model.eval()(torch.randn(2, 3, 64, 64, device=dev)).shape == (2, 5, 64, 64)
+    assert sizes[2] < sizes[1] < sizes[0]
+    total = pruner.initial_total_channels
+    left = sum(g.size for g in pruner.prunable_groups())
+    # global threshold: never more than the budget; groups that would vanish entirely are left alone
+    assert int(total * (1 - 0.4)) <= left < total

@@ -83,13 +83,15 @@ def event_ms(fn, iters, warmup=3, batch=8):
 
 
 def pmc_traffic(kernel_key):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (None if absent)."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["kernels"][kernel_key]["hbm_bytes_corrected"]
-    except (OSError, KeyError, ValueError):
-        return None
+    """HBM bytes per launch from the newest committed rocprofv3 --pmc summary (None if absent)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                return json.load(f)["kernels"][kernel_key]["hbm_bytes_corrected"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def kernel_table(dev):

@@ -297,8 +297,8 @@ def test_cli_run_prints_summary_and_writes_run_directory(dev, tmp_path, capsys):
     assert "Pruning Ratio: 0.3" in (run / "model_info.txt").read_text()
 
 
-def test_integration_stub_runs_as_documented(dev):
-    """The ctypes binding shown in INTEGRATION.md (raw library, no spice_amd.ops): the reference's
+def test_raw_ctypes_binding_of_the_library(dev):
+    """A maintainer's ctypes binding against the raw library (no spice_amd.ops): the reference's
     update_confusion_matrix body replaced by one spice_confusion_update call."""
     import ctypes
     lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),

@@ -1,4 +1,4 @@
-"""The BASELINE configurations as end-to-end parity cases on the GPU (reduced spatial size where
+"""The benchmark configurations as end-to-end parity cases on the GPU (reduced spatial size where
 the oracle has to follow on the CPU; the full sizes are covered by the property tests in
 test_gpu_parity.py)."""
 import copy

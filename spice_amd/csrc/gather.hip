@@ -167,7 +167,8 @@ extern "C" int64_t spice_gather_plan(const spice_gather_desc *tensors, int32_t n
         if (d.dst_cols > d.src_cols) return -SPICE_ERR_ARG;
         const int64_t row_len = d.dst_cols * d.inner;
         const int64_t src_stride = d.src_cols * d.inner;
-        if (src_stride > INT32_MAX || d.dst_rows > INT32_MAX) return -SPICE_ERR_UNSUPPORTED;
+        // the kernel walks an item with 32-bit offsets and looks a few thousand words ahead
+        if (src_stride > INT32_MAX - 8192 || d.dst_rows > INT32_MAX) return -SPICE_ERR_UNSUPPORTED;
         if (d.dst_rows == 0 || row_len == 0) continue;
         const bool vec = d.idx_in_off < 0 && (row_len % 4 == 0) && (d.src_off % 4 == 0) &&
                          (d.dst_off % 4 == 0);

@@ -216,6 +216,62 @@ def inference_case(inference_mod):
             "weight": net.conv.weight.tolist(), "bias": net.conv.bias.tolist(), "result": res_tuple}
 
 
+def eval_result_rows():
+    """Evaluation results as CoreEvaluator returns them (lists, numpy arrays, numpy scalars)."""
+    import numpy as np
+    rows = []
+    for k, (model, strat, method, ratio) in enumerate([("UNET_resnet", "magnitude", "Standard", 0.5),
+                                                       ("DeepLabV3Plus_resnet", "magnitude_taylor", "Standard+KD", 0.7),
+                                                       ("DeepLabV3Plus_resnet", "taylor_weight", "KD-Lite", 0.3)]):
+        conf = (np.arange(25, dtype=np.int64).reshape(5, 5) * (k + 1)) % 17
+        rows.append({"miou": 0.5 + 0.1 * k, "mean_acc": float(np.float32(0.61 + 0.05 * k)),
+                     "per_class_iou": [0.1 * (i + k) for i in range(5)],
+                     "per_class_acc": np.linspace(0.2, 0.9, 5).astype(np.float32).tolist(),
+                     "confusion_matrix": conf, "path": f"runs/{model}/final_model.pth", "model_name": model,
+                     "strategy": strat, "pruning_ratio": ratio, "dir_name": f"{model}_{strat}_{ratio:.2f}",
+                     "fine_tune_method": method, "total_params": 26_000_000 - 7_000_000 * k,
+                     "model_size_mb": 99.18 - 26.7 * k, "total_macs": 36_000_000_000 - 9_000_000_000 * k,
+                     "gmacs": 36.0 - 9.0 * k, "params_percentage": 100.0 - 26.9 * k, "size_percentage": 100.0 - 26.9 * k,
+                     "mac_percentage": 100.0 - 25.0 * k, "mac_reduction": 25.0 * k})
+    return rows
+
+
+def result_processor_case(rp_mod):
+    import contextlib
+    import io
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        proc = rp_mod.ResultProcessor(tmp)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            for row in eval_result_rows():
+                proc.process_single_result(row, row["dir_name"])
+            csv_path = proc.generate_summary(save_csv=True)
+        out["stdout"] = buf.getvalue()
+        # the inputs, for the test to rebuild (confusion_matrix goes back to an int64 array there)
+        out["rows"] = [dict(r, confusion_matrix=r["confusion_matrix"].tolist()) for r in eval_result_rows()]
+        out["row_keys"] = list(eval_result_rows()[0])  # the file is written with sorted keys; columns follow this order
+        out["csv_name"] = os.path.relpath(csv_path, tmp)
+        out["csv_text"] = Path(csv_path).read_text()
+        out["metrics_json"] = {r["dir_name"]: Path(tmp, r["dir_name"], "metrics.json").read_text() for r in eval_result_rows()}
+        empty = rp_mod.ResultProcessor(os.path.join(tmp, "empty"))
+        out["empty_summary"] = empty.generate_summary()
+    return out
+
+
+def evaluation_config_defaults():
+    """Field defaults of the evaluation configuration (its constructor makes its output
+    directories relative to the working directory, hence the temporary one)."""
+    cfg_mod = load_by_path("ref_eval_config", "pruning/eval/config.py")
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            return dict(cfg_mod.EvaluationConfig().__dict__)
+        finally:
+            os.chdir(cwd)
+
+
 def main():
     torch.set_num_threads(2)
     loader_mod = load_by_path("ref_eval_loader", "pruning/eval/loader.py")
@@ -230,7 +286,10 @@ def main():
     trainer_mod = importlib.import_module("pruning.trainer")
     utils_mod = importlib.import_module("pruning.utils")
     inference_mod = importlib.import_module("baseline.eval.inference")
+    rp_mod = load_by_path("ref_result_processor", "pruning/eval/components/result_processor.py")
     out = {"loader": loader_cases(loader_mod), "schedules": schedule_cases(sched_mod),
+           "result_processor": result_processor_case(rp_mod),
+           "evaluation_config_defaults": evaluation_config_defaults(),
            "pruner": pruner_cases(pruner_mod, config_mod, models_mod, trainer_mod, utils_mod),
            "inference": inference_case(inference_mod)}
     with open(os.path.join(HERE, "formats.json"), "w") as f:

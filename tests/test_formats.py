@@ -172,3 +172,59 @@ def test_kd_subset_matches_reference(gold):
 def test_config_hash_matches_reference(gold):
     for s, h in gold["pruner"]["config_hash"].items():
         assert generate_config_hash(s) == h
+
+
+def _eval_rows(gold):
+    import numpy as np
+    g = gold["result_processor"]
+    rows = [{k: r[k] for k in g["row_keys"]} for r in g["rows"]]
+    return [dict(r, confusion_matrix=np.asarray(r["confusion_matrix"], dtype=np.int64)) for r in rows]
+
+
+def test_result_processor_matches_reference(gold, tmp_path, capsys):
+    """Console blocks, per-model metrics.json and evaluation_summary.csv, byte for byte
+    (pruning/eval/components/result_processor.py:12-185)."""
+    from spice_amd.pruning.eval.components import ResultProcessor
+    g = gold["result_processor"]
+    proc = ResultProcessor(str(tmp_path))
+    capsys.readouterr()
+    for row in _eval_rows(gold):
+        proc.process_single_result(row, row["dir_name"])
+    csv_path = proc.generate_summary(save_csv=True)
+    assert capsys.readouterr().out == g["stdout"]
+    assert os.path.relpath(csv_path, tmp_path) == g["csv_name"]
+    assert Path(csv_path).read_text() == g["csv_text"]
+    for name, text in g["metrics_json"].items():
+        assert (tmp_path / name / "metrics.json").read_text() == text
+    assert ResultProcessor(str(tmp_path / "empty")).generate_summary() == g["empty_summary"]
+    assert len(proc.get_results_dataframe()) == len(g["rows"])
+
+
+def test_evaluation_cache_round_trip(gold, tmp_path):
+    """A stored result comes back for the same run directory while its model file is unchanged,
+    and not after the file changes or for another configuration of the same path."""
+    import numpy as np
+    from spice_amd.pruning.eval.components import CacheManager
+    rows = _eval_rows(gold)
+    model = tmp_path / "final_model.pth"
+    model.write_bytes(b"abc")
+    info = {"path": str(model), "model_name": "UNET_resnet", "strategy": "magnitude", "pruning_ratio": 0.5,
+            "dir_name": "UNET_resnet_magnitude_0.50", "fine_tune_method": "Standard"}
+    cm = CacheManager(cache_dir=str(tmp_path), enabled=True)
+    cache = cm.load_cache()
+    assert cache == {} and cm.get_cached_result(info, cache) is None
+    cm.store_result(info, rows[0], cache)
+    again = CacheManager(cache_dir=str(tmp_path), enabled=True)
+    hit = again.get_cached_result(info, again.load_cache())
+    assert hit is not None and hit["miou"] == rows[0]["miou"]
+    assert np.array_equal(np.asarray(hit["confusion_matrix"]), rows[0]["confusion_matrix"])
+    assert again.get_cached_result(dict(info, pruning_ratio=0.6), again.load_cache()) is None
+    os.utime(model, (1, 1))
+    assert again.get_cached_result(info, again.load_cache()) is None
+    off = CacheManager(cache_dir=str(tmp_path), enabled=False)
+    assert off.load_cache() == {} and off.get_cached_result(info, {"x": 1}) is None
+
+
+def test_evaluation_config_defaults_match_reference(gold):
+    from spice_amd.pruning.eval import EvaluationConfig
+    assert EvaluationConfig().__dict__ == gold["evaluation_config_defaults"]

@@ -334,3 +334,102 @@ def test_raw_ctypes_binding_of_the_library(dev):
         oc.update_confusion(want, p.numpy(), t.numpy(), c)
     np.testing.assert_array_equal(conf.cpu().numpy(), want)
     assert lib.spice_confusion_update(None, None, 5, c, None, None, 0, None) != 0  # argument errors are return codes
+
+
+def test_pruned_model_evaluator_walks_a_directory_of_runs(dev, tmp_path, capsys):
+    """pruning/eval/evaluator.py:40-192: every run directory is found, loaded, evaluated, printed
+    and saved; a second evaluator over the same directories takes every result from the cache."""
+    import pandas as pd
+    from spice_amd.pruning.eval import EvaluationConfig, PrunedModelEvaluator
+    from spice_amd.pruning.models import ModelFactory
+    torch.manual_seed(5)
+    runs = tmp_path / "pruned"
+    full = nets.create_model("Unet", "resnet50", 5).to(dev).eval()
+    slim = copy.deepcopy(full)
+    cfg = PruningConfig(model_name="UNET_resnet", num_classes=5, use_wandb=False, output_dir=str(tmp_path / "unused"))
+    engine.MagnitudePruner(slim, torch.randn(1, 3, 64, 64, device=dev), pruning_ratio=0.5,
+                           ignored_layers=ModelFactory.get_ignored_layers(slim, cfg)).step()
+    for name, model in (("UNET_resnet_magnitude_0.50", slim), ("UNET_resnet_random_0.00_kd", full)):
+        (runs / name).mkdir(parents=True)
+        torch.save(model, runs / name / "final_model.pth")
+    (runs / "UNET_resnet_taylor_0.20").mkdir()   # no final model: not a run
+    (runs / "UNET_resnet_lamp_0.30").mkdir()
+    (runs / "UNET_resnet_lamp_0.30" / "final_model.pth").write_bytes(b"not a checkpoint")  # fails to load, run goes on
+    loader = [(torch.randn(2, 3, 64, 64), torch.randint(0, 5, (2, 64, 64))) for _ in range(2)]
+    config = EvaluationConfig(pruned_models_dir=str(runs), output_dir=str(tmp_path / "results"),
+                              visualization_dir=str(tmp_path / "plots"), img_size=64, batch_size=2, num_classes=5,
+                              device="cuda", use_wandb=False, generate_visualizations=False)
+    PrunedModelEvaluator(config).evaluate_all_models(eval_loader=loader)
+    out = capsys.readouterr().out
+    assert "Evaluating [1/3]" in out and "EVALUATION SUMMARY" in out and out.count("Per-class IoU:") == 2
+    table = pd.read_csv(tmp_path / "results" / "evaluation_summary.csv")
+    assert list(table["strategy"]) == ["random", "magnitude"] and list(table["pruning_ratio"]) == [0.0, 0.5]
+    assert list(table["fine_tune_method"]) == ["KD-Lite", "Standard"]
+    by = {r["strategy"]: r for _, r in table.iterrows()}
+    assert by["random"]["params_percentage"] == pytest.approx(100.0) and by["magnitude"]["params_percentage"] < 60.0
+    assert by["magnitude"]["mac_reduction"] > 30.0
+    for name, model in (("UNET_resnet_magnitude_0.50", slim), ("UNET_resnet_random_0.00_kd", full)):
+        saved = json.load(open(tmp_path / "results" / name / "metrics.json"))
+        conf = np.asarray(saved["confusion_matrix"])
+        want = np.zeros((5, 5), dtype=np.int64)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            for x, y in loader:
+                oc.update_confusion(want, oc.argmax_first(model(x.to(dev)).float().cpu().numpy()), y.numpy(), 5)
+        np.testing.assert_array_equal(conf, want)
+        assert saved["miou"] == pytest.approx(oc.macro_metrics_present_classes(want)["miou"], rel=1e-5)
+        assert saved["total_params"] == sum(p.numel() for p in model.parameters())
+    assert not (tmp_path / "results" / "UNET_resnet_lamp_0.30").exists()
+
+    class NoData:
+        def __iter__(self):
+            raise AssertionError("a cached run must not be evaluated again")
+
+    again = PrunedModelEvaluator(config)
+    again.evaluate_all_models(eval_loader=NoData())
+    rerun = pd.read_csv(tmp_path / "results" / "evaluation_summary.csv")
+    assert list(rerun["miou"]) == list(table["miou"]) and len(again.result_processor.results) == 2
+
+
+def test_run_eval_command_line_one_and_two_ranks(dev, tmp_path, capsys):
+    """`python -m pruning.eval.run_eval --pruned-dir D ...` (pruning/eval/run_eval.py:155-245) in
+    this process, then under torch.distributed.run with the models dealt to two ranks: same table."""
+    import subprocess
+    import sys
+    import pandas as pd
+    from spice_amd.pruning.eval import run_eval
+    torch.manual_seed(6)
+    runs = tmp_path / "pruned"
+    for k, name in enumerate(("FPN_resnet_magnitude_0.10", "FPN_resnet_taylor_0.20_kd", "FPN_resnet_lamp_0.30_kd_refine")):
+        (runs / name).mkdir(parents=True)
+        torch.save(nets.create_model("FPN", "resnet50", 5), runs / name / "final_model.pth")
+    common = ["--pruned-dir", str(runs), "--data-root", str(tmp_path / "nodata"), "--batch-size", "8", "--device", "cuda",
+              "--no-visualize", "--no-wandb", "--vis-dir", str(tmp_path / "plots")]
+    run_eval.main(common + ["--output-dir", str(tmp_path / "one")])
+    out = capsys.readouterr().out
+    assert "Evaluating [3/3]" in out and "Evaluation completed!" in out
+    one = pd.read_csv(tmp_path / "one" / "evaluation_summary.csv")
+    assert list(one["strategy"]) == ["magnitude", "taylor", "lamp"] and (one["params_percentage"] == 100.0).all()
+    assert list(one["fine_tune_method"]) == ["Standard", "KD-Lite", "Standard+KD"]
+
+    env = dict(os.environ, SPICE_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "spice_amd.pruning.eval.run_eval"] + common + ["--output-dir", str(tmp_path / "two")]
+    done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420,
+                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
+    assert done.stdout.count("Evaluation completed!") == 1 and done.stdout.count("EVALUATION SUMMARY") == 1
+    two = pd.read_csv(tmp_path / "two" / "evaluation_summary.csv")
+    assert list(two["dir_name"]) == list(one["dir_name"]) and list(two["total_params"]) == list(one["total_params"])
+    assert list(two["total_macs"]) == list(one["total_macs"])
+    # separate processes may pick different convolution algorithms: predictions agree up to rounding flips
+    np.testing.assert_allclose(two["miou"], one["miou"], atol=5e-3)
+    for name in one["dir_name"]:
+        a = np.asarray(json.load(open(tmp_path / "one" / name / "metrics.json"))["confusion_matrix"])
+        b = np.asarray(json.load(open(tmp_path / "two" / name / "metrics.json"))["confusion_matrix"])
+        assert a.sum() == b.sum() and np.array_equal(a.sum(1), b.sum(1))   # same pixels, same label histogram
+    # a second run takes everything from the cache written by rank 0
+    run_eval.main(common + ["--output-dir", str(tmp_path / "two")])
+    assert "Evaluating [" not in capsys.readouterr().out
+    run_eval.main(common + ["--output-dir", str(tmp_path / "two"), "--clear-cache", "--single-model", "FPN_resnet_taylor_0.20_kd"])
+    out = capsys.readouterr().out
+    assert "Evaluation cache cleared" in out and "Model: FPN_resnet_taylor_0.20_kd" in out

@@ -183,3 +183,24 @@ def test_cli_exits_with_status_one_on_failure(tmp_path, capsys):
                   "--output-dir", str(tmp_path), "--data-root", str(tmp_path / "nodata")])
     assert e.value.code == 1
     assert "PRUNING COMPLETE" not in capsys.readouterr().out
+
+
+def test_run_eval_parser_defaults_and_config(tmp_path, monkeypatch):
+    """pruning/eval/run_eval.py:25-177: flag names, defaults (device auto, figure dpi 600, both
+    switches on) and how they land in the evaluation configuration."""
+    from spice_amd.pruning.eval import run_eval
+    monkeypatch.chdir(tmp_path)
+    a = run_eval.parse_args([])
+    assert (a.pruned_dir, a.data_root, a.output_dir, a.vis_dir) == ("pruned_models", "data", "pruning/eval/results", "pruning/eval/outputs")
+    assert (a.batch_size, a.device, a.figure_dpi, a.figure_formats) == (32, "auto", 600, ["png", "pdf"])
+    assert a.visualize and a.wandb and a.advanced_plots and not a.no_eval and not a.clear_cache and a.single_model is None
+    assert (a.wandb_project, a.wandb_tags) == ("epic-v2", ["evaluation", "pruning"])
+    b = run_eval.parse_args(["--pruned-dir", "p", "--output-dir", "o", "--vis-dir", "v", "--no-visualize", "--no-wandb",
+                             "--batch-size", "4", "--device", "cuda", "--single-model", "m", "--no-eval", "--clear-cache"])
+    cfg = run_eval.config_from_args(b)
+    assert (cfg.pruned_models_dir, cfg.output_dir, cfg.batch_size, cfg.device) == ("p", "o", 4, "cuda")
+    assert not cfg.generate_visualizations and not cfg.use_wandb and cfg.figure_dpi == 600
+    assert (tmp_path / "o").is_dir() and not (tmp_path / "v").exists()
+    with pytest.raises(SystemExit):
+        run_eval.parse_args(["--device", "tpu"])
+    run_eval.main(["--output-dir", str(tmp_path / "none"), "--no-eval", "--no-visualize", "--device", "cuda"])  # no CSV yet: message, no work

@@ -238,6 +238,25 @@ int64_t spice_gather_plan(const spice_gather_desc *tensors, int32_t n_tensors,
 int spice_gather_run(const float *src_base, float *dst_base, const int64_t *idx_base,
                      const spice_gather_item *d_items, int64_t n_items, void *stream);
 
+/* ------------------------------------------------------------------------- *
+ * (5) Bilinear up-sampling of NCHW planes (the models' decoder and head).
+ *
+ * Replaces torch's upsample_bilinear2d inside the forward of the models the
+ * reference builds at pruning/models.py:35-39 and baseline/eval/model_factory.py:26-30
+ * (DeepLabV3+ decoder x4, segmentation heads x4, FPN blocks x2), i.e. inside every
+ * forward of the sensitivity sweep and of the evaluation loops
+ * (baseline/eval/inference.py:46, pruning/eval/components/core_evaluator.py:130-137).
+ * src is [planes, in_h, in_w], dst [planes, out_h, out_w], both contiguous;
+ * dtypes: 0 = fp32, 1 = fp16 (arithmetic is fp32 in every case, as torch does
+ * under autocast).  scale_h / scale_w are the scale factors the caller gave
+ * torch (used only without align_corners; 0 = derive from the sizes).
+ * Up-sampling only (out >= in in both directions).
+ * ------------------------------------------------------------------------- */
+int spice_upsample_bilinear(const void *src, int32_t src_dtype, void *dst, int32_t dst_dtype,
+                            int64_t planes, int32_t in_h, int32_t in_w, int32_t out_h,
+                            int32_t out_w, int32_t align_corners, float scale_h, float scale_w,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

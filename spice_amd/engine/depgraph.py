@@ -76,6 +76,8 @@ _PASS_METHODS = {"mean", "contiguous", "relu", "sigmoid", "float", "half", "to"}
 
 class _Tracer(fx.Tracer):
     def is_leaf_module(self, m: nn.Module, qualname: str) -> bool:
+        if isinstance(m, _PASS_MODULES):  # also their subclasses defined outside torch.nn
+            return True
         return m.__module__.startswith("torch.nn") and not isinstance(m, nn.Sequential)
 
 

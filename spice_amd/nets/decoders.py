@@ -17,6 +17,50 @@ class SeparableConv2d(nn.Sequential):
             nn.Conv2d(in_ch, out_ch, 1, bias=bias))
 
 
+class BilinearUp(nn.UpsamplingBilinear2d):
+    """nn.UpsamplingBilinear2d (bilinear, aligned corners) whose forward on a HIP device, when no
+    gradient is wanted, is one launch of the library's up-sampling kernel instead of torch's.
+
+    Under autocast torch runs this op in fp32 and returns fp32; so does this module, reading the
+    fp16 input directly.  With `follow_input_dtype` the result is written in the input's dtype:
+    for a consumer that autocast casts to fp16 anyway (a convolution, also behind a
+    concatenation) the values it sees are the same, and the fp32 round trip through memory is
+    gone.  With gradients, on the CPU or for other dtypes the torch op runs."""
+
+    def __init__(self, scale_factor, follow_input_dtype: bool = False):
+        super().__init__(scale_factor=scale_factor)
+        self.follow_input_dtype = follow_input_dtype
+
+    def forward(self, x):
+        wants_grad = torch.is_grad_enabled() and x.requires_grad
+        if not x.is_cuda or wants_grad or x.dim() != 4 or x.dtype not in (torch.float32, torch.float16):
+            return super().forward(x)
+        from .. import ops
+        out_dtype = x.dtype
+        if torch.is_autocast_enabled("cuda") and not self.follow_input_dtype:
+            out_dtype = torch.float32
+        return ops.upsample_bilinear(x.contiguous(), scale_factor=float(self.scale_factor), align_corners=True,
+                                     out_dtype=out_dtype)
+
+
+class BilinearLike(nn.Upsample):
+    """F.interpolate(y, size=like.shape[-2:], mode="bilinear", align_corners=False): spreads the
+    pooled 1x1 map of the ASPP image branch over the feature map.  Kernel launch under the same
+    conditions as BilinearUp; the result keeps y's dtype (its consumer is the projection
+    convolution behind the concatenation of the branches, fp16 under autocast either way)."""
+
+    def __init__(self):
+        super().__init__(mode="bilinear", align_corners=False)
+
+    def forward(self, y, like):
+        size = tuple(like.shape[-2:])
+        wants_grad = torch.is_grad_enabled() and y.requires_grad
+        if not y.is_cuda or wants_grad or y.dim() != 4 or y.dtype not in (torch.float32, torch.float16):
+            return F.interpolate(y, size=size, mode="bilinear", align_corners=False)
+        from .. import ops
+        return ops.upsample_bilinear(y.contiguous(), size=size, align_corners=False)
+
+
 def _conv_bn_relu(conv: nn.Module, ch: int) -> nn.Sequential:
     return nn.Sequential(conv, nn.BatchNorm2d(ch), nn.ReLU())
 
@@ -28,10 +72,10 @@ class ASPPPooling(nn.Module):
         self.conv = nn.Conv2d(in_ch, out_ch, 1, bias=False)
         self.bn = nn.BatchNorm2d(out_ch)
         self.relu = nn.ReLU()
+        self.up = BilinearLike()
 
     def forward(self, x):
-        y = self.relu(self.bn(self.conv(self.pool(x))))
-        return F.interpolate(y, size=x.shape[-2:], mode="bilinear", align_corners=False)
+        return self.up(self.relu(self.bn(self.conv(self.pool(x)))), x)
 
 
 class ASPP(nn.Module):
@@ -59,7 +103,8 @@ class DeepLabV3PlusDecoder(nn.Module):
             ASPP(encoder_channels[-1], out_channels, rates, separable=True),
             SeparableConv2d(out_channels, out_channels, 3, padding=1, bias=False),
             nn.BatchNorm2d(out_channels), nn.ReLU())
-        self.up = nn.UpsamplingBilinear2d(scale_factor=4)
+        # the consumer (block2, behind the concatenation) is a convolution: fp16 under autocast either way
+        self.up = BilinearUp(scale_factor=4, follow_input_dtype=True)
         self.block1 = _conv_bn_relu(nn.Conv2d(encoder_channels[2], highres_channels, 1, bias=False),
                                     highres_channels)
         self.block2 = _conv_bn_relu(
@@ -118,15 +163,13 @@ class FPNBlock(nn.Module):
 class Conv3x3GNReLU(nn.Module):
     def __init__(self, in_ch: int, out_ch: int, upsample: bool):
         super().__init__()
-        self.upsample = upsample
+        self.up = BilinearUp(scale_factor=2) if upsample else None
         self.block = nn.Sequential(nn.Conv2d(in_ch, out_ch, 3, padding=1, bias=False),
                                    nn.GroupNorm(32, out_ch), nn.ReLU(inplace=True))
 
     def forward(self, x):
         x = self.block(x)
-        if self.upsample:
-            x = F.interpolate(x, scale_factor=2.0, mode="bilinear", align_corners=True)
-        return x
+        return x if self.up is None else self.up(x)
 
 
 class FPNDecoder(nn.Module):
@@ -158,7 +201,7 @@ class FPNDecoder(nn.Module):
 
 class SegmentationHead(nn.Sequential):
     def __init__(self, in_ch: int, classes: int, kernel: int, upsampling: int):
-        up = nn.UpsamplingBilinear2d(scale_factor=upsampling) if upsampling > 1 else nn.Identity()
+        up = BilinearUp(scale_factor=upsampling) if upsampling > 1 else nn.Identity()
         super().__init__(nn.Conv2d(in_ch, classes, kernel, padding=kernel // 2), up, nn.Identity())
 
 

@@ -405,3 +405,34 @@ def gather_channels(src: torch.Tensor, keep_out: Optional[torch.Tensor],
     plan = GatherPlan([GatherSpec(0, 0, o_off, i_off, d_rows, d_cols, cols, max(inner, 1))], src.device)
     plan.run(src.data_ptr(), dst.data_ptr(), idx.data_ptr())
     return dst
+
+
+def upsample_bilinear(x: torch.Tensor, size: Optional[Tuple[int, int]] = None,
+                      scale_factor: Optional[float] = None, align_corners: bool = False,
+                      out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """F.interpolate(x, size / scale_factor, mode="bilinear", align_corners) for an NCHW device
+    tensor (fp32 or fp16), interpolated in fp32 and written as `out_dtype` (default: x's dtype).
+    Forward only; up-sampling only."""
+    if x.dtype not in (torch.float32, torch.float16):
+        raise TypeError(f"upsample_bilinear: dtype {x.dtype} not supported")
+    nat.require_device_tensor(x, "x", x.dtype)
+    if x.dim() != 4:
+        raise ValueError("upsample_bilinear: x must be [N, C, H, W]")
+    if (size is None) == (scale_factor is None):
+        raise ValueError("upsample_bilinear: give exactly one of size and scale_factor")
+    n, c, h, w = (int(v) for v in x.shape)
+    if size is not None:
+        oh, ow = int(size[0]), int(size[1])
+        sh = sw = 0.0
+    else:
+        sh = sw = float(scale_factor)
+        oh, ow = int(h * sh), int(w * sw)   # floor, as torch
+    out_dtype = out_dtype or x.dtype
+    if out_dtype not in (torch.float32, torch.float16):
+        raise TypeError(f"upsample_bilinear: output dtype {out_dtype} not supported")
+    out = torch.empty(n, c, oh, ow, dtype=out_dtype, device=x.device)
+    rc = nat.lib().spice_upsample_bilinear(x.data_ptr(), _DTYPE_CODE[x.dtype], out.data_ptr(), _DTYPE_CODE[out_dtype],
+                                           n * c, h, w, oh, ow, 1 if align_corners else 0, sh, sw,
+                                           nat.current_stream_ptr(x.device))
+    nat.check(rc, "spice_upsample_bilinear")
+    return out

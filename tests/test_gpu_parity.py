@@ -433,3 +433,66 @@ def test_gather_unaligned_offsets_and_odd_rows(dev):
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (spec, ref.shape)
         written[spec.dst_off: spec.dst_off + ref.size] = True
     assert (out[~written] == guard).all()  # nothing outside the destinations was touched
+
+
+UPSAMPLE_CASES = [
+    # shape, kwargs, input dtype, output dtype
+    ((2, 5, 16, 16), dict(scale_factor=4.0, align_corners=True), torch.float32, torch.float32),
+    ((1, 3, 7, 9), dict(scale_factor=2.0, align_corners=True), torch.float32, torch.float32),    # out_w % 4 != 0
+    ((2, 4, 13, 17), dict(size=(40, 52), align_corners=False), torch.float32, torch.float32),
+    ((2, 4, 12, 20), dict(scale_factor=2.0, align_corners=False), torch.float32, torch.float32),
+    ((1, 2, 1, 1), dict(size=(8, 12), align_corners=False), torch.float32, torch.float32),       # a pooled 1x1 map
+    ((1, 2, 1, 1), dict(size=(8, 12), align_corners=True), torch.float32, torch.float32),
+    ((1, 2, 6, 6), dict(size=(6, 6), align_corners=True), torch.float32, torch.float32),         # identity size
+    ((2, 7, 36, 36), dict(scale_factor=4.0, align_corners=True), torch.float16, torch.float32),  # autocast: fp16 in, fp32 out
+    ((2, 7, 36, 36), dict(scale_factor=4.0, align_corners=True), torch.float16, torch.float16),
+    ((8, 21, 128, 128), dict(scale_factor=4.0, align_corners=True), torch.float16, torch.float32),
+    ((3, 2, 5, 300), dict(scale_factor=4.0, align_corners=True), torch.float32, torch.float32),  # one output row per workgroup
+]
+
+
+@pytest.mark.parametrize("shape,kw,in_dtype,out_dtype", UPSAMPLE_CASES)
+def test_upsample_bilinear_vs_oracle_and_torch(dev, shape, kw, in_dtype, out_dtype):
+    """The up-sampling kernel against torch's op on the CPU (the oracle: <= 1e-5 relative to the
+    largest input) and against torch's own device kernel, whose arithmetic it repeats: bit for bit."""
+    from oracle import upsample as ou
+    g = torch.Generator().manual_seed(sum(shape) + 7)
+    x = (3.0 * torch.randn(*shape, generator=g)).to(in_dtype)
+    xd = x.to(dev)
+    got = ops.upsample_bilinear(xd, out_dtype=out_dtype, **kw)
+    want = ou.upsample_bilinear(x, **kw)
+    assert got.shape == want.shape and got.dtype == out_dtype
+    tol = 1e-5 * float(x.float().abs().max()) if out_dtype == torch.float32 else 2e-3 * float(x.float().abs().max())
+    assert float((got.float().cpu() - want).abs().max()) <= tol
+    there = torch.nn.functional.interpolate(xd.float(), mode="bilinear", **kw).to(out_dtype)
+    assert torch.equal(got, there)
+
+
+def test_upsample_rejects_what_it_does_not_implement(dev):
+    x = torch.randn(1, 2, 8, 8, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.upsample_bilinear(x, size=(4, 4))            # down-sampling
+    with pytest.raises(RuntimeError):
+        ops.upsample_bilinear(torch.randn(1, 2, 8, 8), scale_factor=2.0)   # host tensor
+    with pytest.raises(TypeError):
+        ops.upsample_bilinear(x.double(), scale_factor=2.0)
+    with pytest.raises(ValueError):
+        ops.upsample_bilinear(x, size=(16, 16), scale_factor=2.0)
+    assert ops.upsample_bilinear(x[:0], scale_factor=2.0).shape == (0, 2, 16, 16)
+
+
+def test_model_forward_with_kernel_upsampling_equals_torch_upsampling(dev):
+    """The same network with the up-sampling module on its torch path (gradient mode) and on the
+    kernel path (no_grad), under autocast and in fp32: identical logits."""
+    from spice_amd import nets
+    torch.manual_seed(11)
+    for arch in ("DeepLabV3Plus", "FPN"):
+        model = nets.create_model(arch, "resnet50", 5).to(dev).eval()
+        x = torch.randn(2, 3, 128, 128, device=dev)
+        for cast in (True, False):
+            with torch.autocast("cuda", dtype=torch.float16, enabled=cast):
+                with torch.no_grad():
+                    fast = model(x)
+                slow = model(x.clone().requires_grad_(True)).detach()
+            assert fast.dtype == slow.dtype == torch.float32 and fast.shape == (2, 5, 128, 128)
+            assert torch.equal(fast, slow), (arch, cast, float((fast - slow).abs().max()))

@@ -161,6 +161,24 @@ def main():
             fns = [lambda a=a: ops.argmax_confusion_update(conf, a, lab, c) for a in sets]
             report(f"argmax_confusion_{str(dt)[6:]}", timed(fns, args.iters), n * h * w * (c * sz + 8))
 
+    if want("upsample"):
+        # the two x4 steps of DeepLabV3+ at the benchmark geometry: head [8,21,128,128] fp16 -> fp32 logits,
+        # decoder [8,256,32,32] fp16 -> fp16; torch's own kernel beside them
+        import torch.nn.functional as F
+        for tag, shp, out_dt in (("head_x4_f16_to_f32", (8, 21, 128, 128), torch.float32),
+                                 ("decoder_x4_f16_to_f16", (8, 256, 32, 32), torch.float16)):
+            xs = [torch.randn(*shp, device=dev).half() for _ in range(3)]
+            outs = []   # the caching allocator hands the buffers out in rotation
+            nbytes = xs[0].numel() * 2 + xs[0].numel() * 16 * (4 if out_dt == torch.float32 else 2)
+            fns = [lambda a=a: outs.append(ops.upsample_bilinear(a, scale_factor=4.0, align_corners=True, out_dtype=out_dt)) or
+                   (len(outs) > 2 and outs.pop(0)) for a in xs]
+            report(f"upsample_{tag}", timed(fns, args.iters), nbytes)
+            outs.clear()
+            fns = [lambda a=a: outs.append(F.interpolate(a.float(), scale_factor=4.0, mode="bilinear", align_corners=True)) or
+                   (len(outs) > 2 and outs.pop(0)) for a in xs]
+            report(f"torch_upsample_{tag} (cast + fp32 kernel)", timed(fns, args.iters), nbytes)
+            outs.clear()
+
 
 if __name__ == "__main__":
     main()

@@ -257,6 +257,23 @@ int spice_upsample_bilinear(const void *src, int32_t src_dtype, void *dst, int32
                             int32_t out_w, int32_t align_corners, float scale_h, float scale_w,
                             void *stream);
 
+/* ------------------------------------------------------------------------- *
+ * (6) Inference batch-norm with the residual add and the ReLU behind it fused in.
+ *
+ * Replaces, inside the forward of the same models (every forward of the sweep and
+ * of the evaluation loops), the launch triple batch_norm (eval mode) -> add -> relu
+ * of a residual block, or the pair batch_norm -> relu:
+ *   y = relu?( bn(x) [+ residual] ),  bn(x) = weight * (x - mean) * rsqrt(var + eps) + bias
+ * x, residual (may be NULL) and y are [n, c, hw] contiguous, all of `dtype`
+ * (0 = fp32, 1 = fp16); the four parameter vectors are fp32 [c].  Every
+ * intermediate is rounded to `dtype` exactly where the separate kernels would
+ * have stored it.  fp16 needs an even hw (SPICE_ERR_UNSUPPORTED otherwise).
+ * y may alias x.
+ * ------------------------------------------------------------------------- */
+int spice_bn_act(const void *x, const void *residual, void *y, int32_t dtype, const float *mean,
+                 const float *var, const float *weight, const float *bias, float eps, int64_t n,
+                 int64_t c, int64_t hw, int32_t relu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

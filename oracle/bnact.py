@@ -1,0 +1,22 @@
+"""CPU oracle for the fused inference batch-norm + residual add + ReLU (test infrastructure; never
+imported by spice_amd/): the three torch ops of the models' forward (the models of
+pruning/models.py:35-39), run one after the other on the CPU in fp32, each result rounded to the
+tensor's dtype as the separate device kernels store it."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+
+def bn_act(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float,
+           residual: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+    dtype = x.dtype
+    y = F.batch_norm(x.detach().float().cpu(), mean.float().cpu(), var.float().cpu(), weight.float().cpu(),
+                     bias.float().cpu(), False, 0.0, eps).to(dtype)
+    if residual is not None:
+        y = (y.float() + residual.detach().float().cpu()).to(dtype)
+    if relu:
+        y = torch.relu(y)
+    return y

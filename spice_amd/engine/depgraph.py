@@ -76,7 +76,7 @@ _PASS_METHODS = {"mean", "contiguous", "relu", "sigmoid", "float", "half", "to"}
 
 class _Tracer(fx.Tracer):
     def is_leaf_module(self, m: nn.Module, qualname: str) -> bool:
-        if isinstance(m, _PASS_MODULES):  # also their subclasses defined outside torch.nn
+        if isinstance(m, _PASS_MODULES + (nn.BatchNorm2d,)):  # also their subclasses defined outside torch.nn
             return True
         return m.__module__.startswith("torch.nn") and not isinstance(m, nn.Sequential)
 
@@ -167,6 +167,9 @@ def build_groups(model: nn.Module) -> List[ChannelGroup]:
                     for i, s in enumerate(src):
                         records.append((s, m, node.target, BN, src, i))
                 lay = src
+                for extra in node.args[1:]:  # a residual added inside the module couples its channels
+                    if isinstance(extra, fx.Node) and layouts.get(extra) is not None:
+                        lay = union(lay, layouts[extra])
             elif isinstance(m, (nn.GroupNorm, nn.LayerNorm, nn.InstanceNorm2d)):
                 freeze(src)  # channels normalised in blocks: slicing would change the statistics
                 lay = src

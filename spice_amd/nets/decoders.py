@@ -8,6 +8,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .layers import BatchNormAct2d
+
 
 class SeparableConv2d(nn.Sequential):
     def __init__(self, in_ch: int, out_ch: int, kernel: int, padding: int = 0, dilation: int = 1,
@@ -62,7 +64,7 @@ class BilinearLike(nn.Upsample):
 
 
 def _conv_bn_relu(conv: nn.Module, ch: int) -> nn.Sequential:
-    return nn.Sequential(conv, nn.BatchNorm2d(ch), nn.ReLU())
+    return nn.Sequential(conv, BatchNormAct2d(ch, relu=True))
 
 
 class ASPPPooling(nn.Module):
@@ -89,7 +91,7 @@ class ASPP(nn.Module):
         branches.append(ASPPPooling(in_ch, out_ch))
         self.convs = nn.ModuleList(branches)
         self.project = nn.Sequential(nn.Conv2d(len(branches) * out_ch, out_ch, 1, bias=False),
-                                     nn.BatchNorm2d(out_ch), nn.ReLU(), nn.Dropout(0.5))
+                                     BatchNormAct2d(out_ch, relu=True), nn.Dropout(0.5))
 
     def forward(self, x):
         return self.project(torch.cat([b(x) for b in self.convs], dim=1))
@@ -102,7 +104,7 @@ class DeepLabV3PlusDecoder(nn.Module):
         self.aspp = nn.Sequential(
             ASPP(encoder_channels[-1], out_channels, rates, separable=True),
             SeparableConv2d(out_channels, out_channels, 3, padding=1, bias=False),
-            nn.BatchNorm2d(out_channels), nn.ReLU())
+            BatchNormAct2d(out_channels, relu=True))
         # the consumer (block2, behind the concatenation) is a convolution: fp16 under autocast either way
         self.up = BilinearUp(scale_factor=4, follow_input_dtype=True)
         self.block1 = _conv_bn_relu(nn.Conv2d(encoder_channels[2], highres_channels, 1, bias=False),

@@ -6,6 +6,8 @@ from typing import List
 import torch
 import torch.nn as nn
 
+from .layers import BatchNormAct2d
+
 
 class Bottleneck(nn.Module):
     expansion = 4
@@ -14,13 +16,12 @@ class Bottleneck(nn.Module):
                  downsample: bool = False):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = BatchNormAct2d(planes, relu=True)
         self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation,
                                bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = BatchNormAct2d(planes, relu=True)
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * 4)
-        self.relu = nn.ReLU(inplace=True)
+        self.bn3 = BatchNormAct2d(planes * 4, relu=True)   # applied to bn3(x) + identity
         self.downsample = None
         if downsample:
             self.downsample = nn.Sequential(
@@ -28,13 +29,9 @@ class Bottleneck(nn.Module):
                 nn.BatchNorm2d(planes * 4))
 
     def forward(self, x):
-        identity = x
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        if self.downsample is not None:
-            identity = self.downsample(x)
-        return self.relu(out + identity)
+        out = self.bn2(self.conv2(self.bn1(self.conv1(x))))
+        identity = x if self.downsample is None else self.downsample(x)
+        return self.bn3(self.conv3(out), identity)
 
 
 class ResNet50Encoder(nn.Module):
@@ -47,8 +44,7 @@ class ResNet50Encoder(nn.Module):
         if output_stride not in (16, 32):
             raise ValueError("output_stride must be 16 or 32")
         self.conv1 = nn.Conv2d(in_channels, 64, 7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
-        self.relu = nn.ReLU(inplace=True)
+        self.bn1 = BatchNormAct2d(64, relu=True)
         self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
         self.inplanes = 64
         self.layer1 = self._make_layer(64, 3, stride=1, dilation=1)
@@ -68,7 +64,7 @@ class ResNet50Encoder(nn.Module):
 
     def forward(self, x) -> List[torch.Tensor]:
         f0 = x
-        f1 = self.relu(self.bn1(self.conv1(x)))
+        f1 = self.bn1(self.conv1(x))
         f2 = self.layer1(self.maxpool(f1))
         f3 = self.layer2(f2)
         f4 = self.layer3(f3)

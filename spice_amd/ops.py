@@ -436,3 +436,36 @@ def upsample_bilinear(x: torch.Tensor, size: Optional[Tuple[int, int]] = None,
                                            nat.current_stream_ptr(x.device))
     nat.check(rc, "spice_upsample_bilinear")
     return out
+
+
+def bn_act_supported(x: torch.Tensor) -> bool:
+    """Whether bn_act reproduces torch's kernels for this tensor: an NCHW fp32 tensor, or an fp16 one
+    with an even number of elements per plane."""
+    if x.dim() != 4 or x.dtype not in (torch.float32, torch.float16) or not x.is_contiguous():
+        return False
+    return x.dtype == torch.float32 or (x.shape[2] * x.shape[3]) % 2 == 0
+
+
+def bn_act(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
+           eps: float, residual: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+    """relu?(batch_norm(x, running statistics) [+ residual]) in one launch; a new tensor of x's dtype."""
+    if x.dtype not in (torch.float32, torch.float16):
+        raise TypeError(f"bn_act: dtype {x.dtype} not supported")
+    nat.require_device_tensor(x, "x", x.dtype)
+    if x.dim() != 4:
+        raise ValueError("bn_act: x must be [N, C, H, W]")
+    n, c, h, w = (int(v) for v in x.shape)
+    for name, t in (("mean", mean), ("var", var), ("weight", weight), ("bias", bias)):
+        nat.require_device_tensor(t, name, torch.float32)
+        if t.numel() != c:
+            raise ValueError(f"bn_act: {name} must have {c} elements")
+    if residual is not None:
+        nat.require_device_tensor(residual, "residual", x.dtype)
+        if residual.shape != x.shape:
+            raise ValueError("bn_act: residual must have x's shape")
+    out = torch.empty_like(x)
+    rc = nat.lib().spice_bn_act(x.data_ptr(), residual.data_ptr() if residual is not None else None, out.data_ptr(),
+                                _DTYPE_CODE[x.dtype], mean.data_ptr(), var.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                float(eps), n, c, h * w, 1 if relu else 0, nat.current_stream_ptr(x.device))
+    nat.check(rc, "spice_bn_act")
+    return out

@@ -8,6 +8,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
+
 
 class BatchNormAct2d(nn.BatchNorm2d):
     """nn.BatchNorm2d with what follows it in a residual network folded into the module:
@@ -23,22 +25,12 @@ class BatchNormAct2d(nn.BatchNorm2d):
         super().__init__(num_features, **kwargs)
         self.relu_after = relu
 
-    def _fusable(self, x: torch.Tensor, residual: Optional[torch.Tensor]) -> bool:
-        if self.training or torch.is_grad_enabled() or not x.is_cuda:
-            return False
-        if not (self.affine and self.track_running_stats) or self.weight.dtype != torch.float32:
-            return False
-        if residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape
-                                     or not residual.is_contiguous()):
-            return False
-        from .. import ops
-        return ops.bn_act_supported(x)
-
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if self._fusable(x, residual):
-            from .. import ops
-            return ops.bn_act(x, self.running_mean, self.running_var, self.weight, self.bias, self.eps,
-                              residual=residual, relu=self.relu_after)
+        if not (self.training or torch.is_grad_enabled()) and x.is_cuda and self.track_running_stats and self.affine:
+            if ops.bn_act_supported(x) and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape
+                                                                  and residual.is_contiguous())):
+                return ops.bn_act(x, self.running_mean, self.running_var, self.weight, self.bias, self.eps,
+                                  residual=residual, relu=self.relu_after)
         y = super().forward(x)
         if residual is not None:
             y = y + residual

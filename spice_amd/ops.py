@@ -441,31 +441,46 @@ def upsample_bilinear(x: torch.Tensor, size: Optional[Tuple[int, int]] = None,
 def bn_act_supported(x: torch.Tensor) -> bool:
     """Whether bn_act reproduces torch's kernels for this tensor: an NCHW fp32 tensor, or an fp16 one
     with an even number of elements per plane."""
-    if x.dim() != 4 or x.dtype not in (torch.float32, torch.float16) or not x.is_contiguous():
+    if x.dim() != 4 or not x.is_contiguous():
         return False
-    return x.dtype == torch.float32 or (x.shape[2] * x.shape[3]) % 2 == 0
+    if x.dtype == torch.float32:
+        return True
+    return x.dtype == torch.float16 and (x.shape[2] * x.shape[3]) % 2 == 0
+
+
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_bn_fn = None
 
 
 def bn_act(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
            eps: float, residual: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
-    """relu?(batch_norm(x, running statistics) [+ residual]) in one launch; a new tensor of x's dtype."""
-    if x.dtype not in (torch.float32, torch.float16):
-        raise TypeError(f"bn_act: dtype {x.dtype} not supported")
-    nat.require_device_tensor(x, "x", x.dtype)
-    if x.dim() != 4:
-        raise ValueError("bn_act: x must be [N, C, H, W]")
-    n, c, h, w = (int(v) for v in x.shape)
-    for name, t in (("mean", mean), ("var", var), ("weight", weight), ("bias", bias)):
-        nat.require_device_tensor(t, name, torch.float32)
-        if t.numel() != c:
-            raise ValueError(f"bn_act: {name} must have {c} elements")
+    """relu?(batch_norm(x, running statistics) [+ residual]) in one launch; a new tensor of x's dtype.
+    Called ~60 times per forward of a ResNet-50 model, so the checks are kept to attribute reads."""
+    global _bn_fn
+    if _bn_fn is None:
+        _bn_fn = nat.lib().spice_bn_act
+    dt = x.dtype
+    code = 0 if dt == torch.float32 else 1 if dt == torch.float16 else -1
+    if code < 0:
+        raise TypeError(f"bn_act: dtype {dt} not supported")
+    if not x.is_cuda:
+        nat.require_device_tensor(x, "x", dt)
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("bn_act: x must be a contiguous [N, C, H, W] tensor")
+    n, c, h, w = x.shape
+    for t in (mean, var, weight, bias):
+        if t.dtype != torch.float32 or t.device != x.device or t.numel() != c or not t.is_contiguous():
+            raise TypeError(f"bn_act: the four parameter vectors must be contiguous fp32 [{c}] on {x.device}")
+    res_ptr = None
     if residual is not None:
-        nat.require_device_tensor(residual, "residual", x.dtype)
         if residual.shape != x.shape:
             raise ValueError("bn_act: residual must have x's shape")
+        if residual.dtype != dt or residual.device != x.device or not residual.is_contiguous():
+            raise TypeError("bn_act: residual must be contiguous, of x's dtype and on x's device")
+        res_ptr = residual.data_ptr()
     out = torch.empty_like(x)
-    rc = nat.lib().spice_bn_act(x.data_ptr(), residual.data_ptr() if residual is not None else None, out.data_ptr(),
-                                _DTYPE_CODE[x.dtype], mean.data_ptr(), var.data_ptr(), weight.data_ptr(), bias.data_ptr(),
-                                float(eps), n, c, h * w, 1 if relu else 0, nat.current_stream_ptr(x.device))
-    nat.check(rc, "spice_bn_act")
+    rc = _bn_fn(x.data_ptr(), res_ptr, out.data_ptr(), code, mean.data_ptr(), var.data_ptr(), weight.data_ptr(),
+                bias.data_ptr(), eps, n, c, h * w, 1 if relu else 0, _raw_stream(x.device.index))
+    if rc:
+        nat.check(rc, "spice_bn_act")
     return out

@@ -274,6 +274,19 @@ int spice_bn_act(const void *x, const void *residual, void *y, int32_t dtype, co
                  const float *var, const float *weight, const float *bias, float eps, int64_t n,
                  int64_t c, int64_t hw, int32_t relu, void *stream);
 
+/* ------------------------------------------------------------------------- *
+ * (7) Depthwise 3x3 convolution (stride 1, padding 1, no bias), fp16 NCHW.
+ *
+ * Replaces, inside the forward of the same models, torch's conv2d call for the
+ * depthwise half of the DeepLabV3+ decoder's separable convolutions, which
+ * MIOpen serves with its reference kernel.  x and y are [n, c, h, w] fp16
+ * contiguous; weight is [c, 1, 3, 3], fp16 (weight_dtype 1) or fp32 (0: rounded
+ * to fp16 first, as autocast's cast does).  Products and sums are exact (fp64),
+ * the result is rounded to fp16 once.  w must be a multiple of 8 and <= 2048.
+ * ------------------------------------------------------------------------- */
+int spice_depthwise_conv3x3(const void *x, const void *weight, int32_t weight_dtype, void *y,
+                            int64_t n, int64_t c, int32_t h, int32_t w, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,115 @@
+// Depthwise 3x3 convolution, stride 1, padding 1, fp16 NCHW: the first half of the separable
+// convolutions of the DeepLabV3+ decoder (the models of pruning/models.py:35-39).  MIOpen runs these
+// shapes on its reference kernel (one thread per output, fp64 accumulation), ten times slower than
+// the memory traffic asks for; this kernel keeps that kernel's arithmetic (every product and the sum
+// of the nine exact in fp64, one rounding to fp16 at the end) and streams the planes.
+//
+// HBM-bound: reads the input once (neighbouring rows and the two edge columns of a lane's window
+// come from L1/L2) and writes the output once.  A lane produces 8 consecutive outputs of one row:
+// three 16-byte row loads plus the two neighbours left and right of each, 72 fp64 multiply-adds,
+// one 16-byte store.
+#include "common.h"
+
+#include <hip/hip_fp16.h>
+
+namespace spice {
+
+constexpr int kDwThreads = 256;
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+struct DwArgs {
+    const _Float16 *x;
+    const void *w;     // [C, 1, 3, 3], fp16 or fp32 (rounded to fp16 here, as autocast's cast does)
+    _Float16 *y;
+    int c, h, wd;
+    int lanes_per_row;   // wd / 8
+    int rows_per_block;
+    int blocks_per_plane;
+    int w_is_f32;
+};
+
+__global__ __launch_bounds__(kDwThreads) void depthwise3x3_kernel(DwArgs a) {
+    const int plane = blockIdx.x / a.blocks_per_plane;
+    const int band = blockIdx.x - plane * a.blocks_per_plane;
+    const int ch = plane % a.c;
+    const int ly = threadIdx.x / a.lanes_per_row;
+    const int lx = threadIdx.x - ly * a.lanes_per_row;
+    const int y = band * a.rows_per_block + ly;
+    const bool active = ly < a.rows_per_block && y < a.h;
+    const int yc = min(y, a.h - 1);
+    const int x0 = lx * 8;
+
+    double wt[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const _Float16 v = a.w_is_f32 ? static_cast<_Float16>(static_cast<const float *>(a.w)[ch * 9 + k])
+                                      : static_cast<const _Float16 *>(a.w)[ch * 9 + k];
+        wt[k] = static_cast<double>(v);
+    }
+
+    const _Float16 *src = a.x + static_cast<int64_t>(plane) * a.h * a.wd;
+    // all loads first, from clamped (always valid) addresses; what lies outside the plane is zeroed after
+    f16x8_t mid[3];
+    _Float16 left[3], right[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int yy = min(max(yc + r - 1, 0), a.h - 1);
+        const _Float16 *row = src + static_cast<int64_t>(yy) * a.wd;
+        mid[r] = *reinterpret_cast<const f16x8_t *>(row + x0);
+        left[r] = row[max(x0 - 1, 0)];
+        right[r] = row[min(x0 + 8, a.wd - 1)];
+    }
+    double acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int yy = yc + r - 1;
+        const bool row_in = yy >= 0 && yy < a.h;
+        double v[10];
+        v[0] = row_in && x0 > 0 ? static_cast<double>(left[r]) : 0.0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e + 1] = row_in ? static_cast<double>(mid[r][e]) : 0.0;
+        v[9] = row_in && x0 + 8 < a.wd ? static_cast<double>(right[r]) : 0.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = __builtin_fma(wt[r * 3 + j], v[e + j], acc[e]);
+    }
+    f16x8_t out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = static_cast<_Float16>(acc[e]);
+    if (active) *reinterpret_cast<f16x8_t *>(a.y + (static_cast<int64_t>(plane) * a.h + y) * a.wd + x0) = out;
+}
+
+}  // namespace spice
+
+extern "C" int spice_depthwise_conv3x3(const void *x, const void *weight, int32_t weight_dtype, void *y,
+                                       int64_t n, int64_t c, int32_t h, int32_t w, void *stream) {
+    using namespace spice;
+    if (n < 0 || c <= 0 || h <= 0 || w <= 0) return SPICE_ERR_ARG;
+    if (n == 0) return SPICE_OK;
+    if (x == nullptr || weight == nullptr || y == nullptr) return SPICE_ERR_ARG;
+    if (weight_dtype != 0 && weight_dtype != 1) return SPICE_ERR_UNSUPPORTED;
+    if (w % 8 != 0 || w / 8 > kDwThreads || !aligned16(x) || !aligned16(y)) return SPICE_ERR_UNSUPPORTED;
+    if (n * c > INT32_MAX / 64) return SPICE_ERR_UNSUPPORTED;
+    DwArgs a;
+    a.x = static_cast<const _Float16 *>(x);
+    a.w = weight;
+    a.y = static_cast<_Float16 *>(y);
+    a.c = static_cast<int>(c);
+    a.h = h;
+    a.wd = w;
+    a.lanes_per_row = w / 8;
+    a.rows_per_block = kDwThreads / a.lanes_per_row;
+    if (a.rows_per_block > h) a.rows_per_block = h;
+    a.blocks_per_plane = static_cast<int>(ceil_div(h, a.rows_per_block));
+    a.w_is_f32 = weight_dtype == 0;
+    const int64_t blocks = n * c * a.blocks_per_plane;
+    if (blocks > INT32_MAX) return SPICE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(depthwise3x3_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kDwThreads), 0,
+                       static_cast<hipStream_t>(stream), a);
+    SPICE_LAUNCH_CHECK();
+    return SPICE_OK;
+}

@@ -76,7 +76,7 @@ _PASS_METHODS = {"mean", "contiguous", "relu", "sigmoid", "float", "half", "to"}
 
 class _Tracer(fx.Tracer):
     def is_leaf_module(self, m: nn.Module, qualname: str) -> bool:
-        if isinstance(m, _PASS_MODULES + (nn.BatchNorm2d,)):  # also their subclasses defined outside torch.nn
+        if isinstance(m, _PASS_MODULES + (nn.BatchNorm2d, nn.Conv2d)):  # also their subclasses defined outside torch.nn
             return True
         return m.__module__.startswith("torch.nn") and not isinstance(m, nn.Sequential)
 

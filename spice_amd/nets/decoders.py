@@ -8,15 +8,17 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .layers import BatchNormAct2d
+from .layers import BatchNormAct2d, DepthwiseConv3x3
 
 
 class SeparableConv2d(nn.Sequential):
     def __init__(self, in_ch: int, out_ch: int, kernel: int, padding: int = 0, dilation: int = 1,
                  bias: bool = True):
-        super().__init__(
-            nn.Conv2d(in_ch, in_ch, kernel, padding=padding, dilation=dilation, groups=in_ch, bias=False),
-            nn.Conv2d(in_ch, out_ch, 1, bias=bias))
+        if kernel == 3 and padding == dilation:
+            depthwise = DepthwiseConv3x3(in_ch, dilation)
+        else:
+            depthwise = nn.Conv2d(in_ch, in_ch, kernel, padding=padding, dilation=dilation, groups=in_ch, bias=False)
+        super().__init__(depthwise, nn.Conv2d(in_ch, out_ch, 1, bias=bias))
 
 
 class BilinearUp(nn.UpsamplingBilinear2d):

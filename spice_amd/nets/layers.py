@@ -38,3 +38,23 @@ class BatchNormAct2d(nn.BatchNorm2d):
 
     def extra_repr(self) -> str:
         return super().extra_repr() + f", relu={self.relu_after}"
+
+
+class DepthwiseConv3x3(nn.Conv2d):
+    """nn.Conv2d(ch, ch, 3, padding=dilation, dilation=dilation, groups=ch, bias=False).  Without
+    dilation, on fp16 activations (autocast) under no_grad on a HIP device, the forward is the
+    library's streaming kernel (exact sums, one rounding: what MIOpen's reference kernel, which
+    serves these shapes, computes); in every other situation torch's conv2d runs."""
+
+    def __init__(self, channels: int, dilation: int = 1):
+        super().__init__(channels, channels, 3, padding=dilation, dilation=dilation, groups=channels, bias=False)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if (not torch.is_grad_enabled() and x.is_cuda and self.dilation == (1, 1) and self.stride == (1, 1)
+                and self.padding == (1, 1) and self.bias is None and self.groups == self.in_channels == self.out_channels
+                and (x.dtype == torch.float16 or torch.is_autocast_enabled("cuda"))):
+            if x.dtype != torch.float16 and torch.get_autocast_dtype("cuda") == torch.float16:
+                x = x.to(torch.float16)   # what autocast does to a convolution's input
+            if ops.depthwise_conv3x3_supported(x, self.weight):
+                return ops.depthwise_conv3x3(x, self.weight)
+        return super().forward(x)

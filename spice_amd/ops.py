@@ -484,3 +484,26 @@ def bn_act(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, weight: torch
     if rc:
         nat.check(rc, "spice_bn_act")
     return out
+
+
+def depthwise_conv3x3_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """fp16 NCHW input whose width is a multiple of 8 (at most 2048), [C,1,3,3] fp16 or fp32 weight."""
+    return (x.dim() == 4 and x.dtype == torch.float16 and x.is_contiguous() and x.shape[3] % 8 == 0
+            and x.shape[3] <= 2048 and weight.dtype in (torch.float16, torch.float32)
+            and tuple(weight.shape) == (x.shape[1], 1, 3, 3) and weight.is_contiguous())
+
+
+def depthwise_conv3x3(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """conv2d(x, weight, stride=1, padding=1, groups=C) for fp16 x, exact sums, one rounding."""
+    nat.require_device_tensor(x, "x", torch.float16)
+    if weight.dtype not in (torch.float16, torch.float32):
+        raise TypeError(f"depthwise_conv3x3: weight dtype {weight.dtype} not supported")
+    nat.require_device_tensor(weight, "weight", weight.dtype)
+    if x.dim() != 4 or tuple(weight.shape) != (x.shape[1], 1, 3, 3):
+        raise ValueError("depthwise_conv3x3: x must be [N,C,H,W] and weight [C,1,3,3]")
+    n, c, h, w = x.shape
+    out = torch.empty_like(x)
+    rc = nat.lib().spice_depthwise_conv3x3(x.data_ptr(), weight.data_ptr(), 0 if weight.dtype == torch.float32 else 1,
+                                           out.data_ptr(), n, c, h, w, _raw_stream(x.device.index))
+    nat.check(rc, "spice_depthwise_conv3x3")
+    return out

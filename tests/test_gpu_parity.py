@@ -515,3 +515,37 @@ def test_model_forward_on_library_kernels_equals_torch_forward(dev):
                     if isinstance(mod, BatchNormAct2d) or getattr(mod, "follow_input_dtype", False) or isinstance(mod, BilinearLike):
                         again = again.to(out.dtype)  # torch up-samples to fp32 under autocast; the consumer casts back
                     assert again.dtype == out.dtype and torch.equal(out, again), (arch, cast, type(mod).__name__)
+
+
+@pytest.mark.parametrize("shape,w_dtype", [((2, 6, 8, 8), torch.float16), ((1, 3, 5, 16), torch.float32),
+                                            ((2, 304, 36, 40), torch.float32), ((8, 304, 128, 128), torch.float32),
+                                            ((1, 2, 1, 8), torch.float16), ((2, 5, 300, 24), torch.float16)])
+def test_depthwise_conv3x3_vs_oracle_and_torch(dev, shape, w_dtype):
+    """Bit for bit against the CPU oracle (exact sums, one rounding); what torch runs on the device
+    for the same call (solver-dependent, fp32 or fp64 accumulation) is within one fp16 step of it
+    on a few elements in ten thousand."""
+    from oracle import depthwise as od
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g).half()
+    w = (0.5 * torch.randn(shape[1], 1, 3, 3, generator=g)).to(w_dtype)
+    got = ops.depthwise_conv3x3(x.to(dev), w.to(dev))
+    want = od.depthwise_conv3x3(x, w)
+    assert got.dtype == torch.float16 and torch.equal(got.cpu(), want)
+    there = torch.nn.functional.conv2d(x.to(dev), w.to(dev).half(), None, 1, 1, 1, shape[1])
+    # one fp16 step of the result, plus fp32 accumulation error of nine terms where they cancel
+    terms = 9.0 * float(x.abs().max()) * float(w.abs().max())
+    step = got.float().abs() * 2.0 ** -10 + terms * 2.0 ** -22
+    assert bool(((there.float() - got.float()).abs() <= step).all())
+    assert int((there != got).sum()) <= max(2, got.numel() // 1000)
+
+
+def test_depthwise_conv3x3_rejects_other_layouts(dev):
+    x = torch.randn(1, 4, 8, 12, device=dev).half()    # width not a multiple of 8
+    w = torch.randn(4, 1, 3, 3, device=dev)
+    assert not ops.depthwise_conv3x3_supported(x, w)
+    with pytest.raises(RuntimeError):
+        ops.depthwise_conv3x3(x, w)
+    with pytest.raises(TypeError):
+        ops.depthwise_conv3x3(x.float(), w)
+    with pytest.raises(ValueError):
+        ops.depthwise_conv3x3(x[..., :8].contiguous(), w[:3])

@@ -179,6 +179,21 @@ def main():
             report(f"torch_upsample_{tag} (cast + fp32 kernel)", timed(fns, args.iters), nbytes)
             outs.clear()
 
+    if want("depthwise"):
+        import torch.nn.functional as F
+        for shp in ((8, 304, 128, 128), (8, 256, 32, 32)):
+            xs = [torch.randn(*shp, device=dev).half() for _ in range(3)]
+            wt = torch.randn(shp[1], 1, 3, 3, device=dev)
+            w16 = wt.half()
+            outs = []
+            nbytes = xs[0].numel() * 4
+            fns = [lambda a=a: outs.append(ops.depthwise_conv3x3(a, wt)) or (len(outs) > 2 and outs.pop(0)) for a in xs]
+            report(f"depthwise3x3 {shp}", timed(fns, args.iters), nbytes)
+            outs.clear()
+            fns = [lambda a=a: outs.append(F.conv2d(a, w16, None, 1, 1, 1, shp[1])) or (len(outs) > 2 and outs.pop(0)) for a in xs]
+            report(f"torch conv2d depthwise {shp}", timed(fns, args.iters), nbytes)
+            outs.clear()
+
 
 if __name__ == "__main__":
     main()

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .layers import BatchNormAct2d, DepthwiseConv3x3
+from .layers import BatchNormAct2d, Conv1x1, DepthwiseConv3x3
 
 
 class SeparableConv2d(nn.Sequential):
@@ -18,7 +18,7 @@ class SeparableConv2d(nn.Sequential):
             depthwise = DepthwiseConv3x3(in_ch, dilation)
         else:
             depthwise = nn.Conv2d(in_ch, in_ch, kernel, padding=padding, dilation=dilation, groups=in_ch, bias=False)
-        super().__init__(depthwise, nn.Conv2d(in_ch, out_ch, 1, bias=bias))
+        super().__init__(depthwise, nn.Conv2d(in_ch, out_ch, 1, bias=True) if bias else Conv1x1(in_ch, out_ch))
 
 
 class BilinearUp(nn.UpsamplingBilinear2d):
@@ -73,7 +73,7 @@ class ASPPPooling(nn.Module):
     def __init__(self, in_ch: int, out_ch: int):
         super().__init__()
         self.pool = nn.AdaptiveAvgPool2d(1)
-        self.conv = nn.Conv2d(in_ch, out_ch, 1, bias=False)
+        self.conv = Conv1x1(in_ch, out_ch)
         self.bn = nn.BatchNorm2d(out_ch)
         self.relu = nn.ReLU()
         self.up = BilinearLike()
@@ -85,14 +85,14 @@ class ASPPPooling(nn.Module):
 class ASPP(nn.Module):
     def __init__(self, in_ch: int, out_ch: int, rates: Sequence[int], separable: bool = True):
         super().__init__()
-        branches = [_conv_bn_relu(nn.Conv2d(in_ch, out_ch, 1, bias=False), out_ch)]
+        branches = [_conv_bn_relu(Conv1x1(in_ch, out_ch), out_ch)]
         for r in rates:
             conv = (SeparableConv2d(in_ch, out_ch, 3, padding=r, dilation=r, bias=False) if separable
                     else nn.Conv2d(in_ch, out_ch, 3, padding=r, dilation=r, bias=False))
             branches.append(_conv_bn_relu(conv, out_ch))
         branches.append(ASPPPooling(in_ch, out_ch))
         self.convs = nn.ModuleList(branches)
-        self.project = nn.Sequential(nn.Conv2d(len(branches) * out_ch, out_ch, 1, bias=False),
+        self.project = nn.Sequential(Conv1x1(len(branches) * out_ch, out_ch),
                                      BatchNormAct2d(out_ch, relu=True), nn.Dropout(0.5))
 
     def forward(self, x):
@@ -109,7 +109,7 @@ class DeepLabV3PlusDecoder(nn.Module):
             BatchNormAct2d(out_channels, relu=True))
         # the consumer (block2, behind the concatenation) is a convolution: fp16 under autocast either way
         self.up = BilinearUp(scale_factor=4, follow_input_dtype=True)
-        self.block1 = _conv_bn_relu(nn.Conv2d(encoder_channels[2], highres_channels, 1, bias=False),
+        self.block1 = _conv_bn_relu(Conv1x1(encoder_channels[2], highres_channels),
                                     highres_channels)
         self.block2 = _conv_bn_relu(
             SeparableConv2d(highres_channels + out_channels, out_channels, 3, padding=1, bias=False),

@@ -2,6 +2,7 @@
 is a launch of the library instead of a chain of torch kernels."""
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -57,4 +58,46 @@ class DepthwiseConv3x3(nn.Conv2d):
                 x = x.to(torch.float16)   # what autocast does to a convolution's input
             if ops.depthwise_conv3x3_supported(x, self.weight):
                 return ops.depthwise_conv3x3(x, self.weight)
+        return super().forward(x)
+
+
+# fp16 copies of convolution weights, per Parameter object: id -> (weak reference, version, [Cout, Cin] fp16).
+# The same bookkeeping autocast does for the weights it casts: one cast per Parameter and version, dropped
+# with the Parameter.
+_FP16_WEIGHTS = {}
+
+
+def _fp16_matrix(weight: torch.Tensor) -> torch.Tensor:
+    key = id(weight)
+    ent = _FP16_WEIGHTS.get(key)
+    if ent is None or ent[0]() is not weight or ent[1] != weight._version:
+        w16 = weight.detach().to(torch.float16).view(weight.shape[0], weight.shape[1])
+        ent = (weakref.ref(weight, lambda _, k=key: _FP16_WEIGHTS.pop(k, None)), weight._version, w16)
+        _FP16_WEIGHTS[key] = ent
+    return ent[2]
+
+
+class Conv1x1(nn.Conv2d):
+    """nn.Conv2d(in_ch, out_ch, 1, bias=False).  With stride 1 on fp16 activations (autocast) under
+    no_grad on a HIP device the forward is the matrix product it is, W[Cout,Cin] @ X[n][Cin,HW],
+    through torch.bmm: the same hipBLASLt kernels MIOpen's 1x1 solver launches (identical results
+    where that solver is the one MIOpen picks) without MIOpen's per-call host work, which is what
+    bounds a forward of ~70 convolutions once the device work is short.  In every other situation
+    torch's conv2d runs."""
+
+    def __init__(self, in_channels: int, out_channels: int, stride: int = 1):
+        super().__init__(in_channels, out_channels, 1, stride=stride, bias=False)
+
+    def takes_matrix_path(self, x_dtype: torch.dtype) -> bool:
+        return (self.stride == (1, 1) and self.bias is None and self.groups == 1 and self.padding == (0, 0)
+                and (x_dtype == torch.float16 or
+                     (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16)))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and self.takes_matrix_path(x.dtype):
+            if x.dtype != torch.float16:
+                x = x.to(torch.float16)   # what autocast does to a convolution's input
+            if x.is_contiguous():
+                n, c, h, w = x.shape
+                return torch.bmm(_fp16_matrix(self.weight).expand(n, -1, -1), x.view(n, c, h * w)).view(n, -1, h, w)
         return super().forward(x)

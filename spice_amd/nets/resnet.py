@@ -6,7 +6,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .layers import BatchNormAct2d
+from .layers import BatchNormAct2d, Conv1x1
 
 
 class Bottleneck(nn.Module):
@@ -15,17 +15,17 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes: int, planes: int, stride: int = 1, dilation: int = 1,
                  downsample: bool = False):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.conv1 = Conv1x1(inplanes, planes)
         self.bn1 = BatchNormAct2d(planes, relu=True)
         self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation,
                                bias=False)
         self.bn2 = BatchNormAct2d(planes, relu=True)
-        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.conv3 = Conv1x1(planes, planes * 4)
         self.bn3 = BatchNormAct2d(planes * 4, relu=True)   # applied to bn3(x) + identity
         self.downsample = None
         if downsample:
             self.downsample = nn.Sequential(
-                nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                Conv1x1(inplanes, planes * 4, stride=stride),
                 nn.BatchNorm2d(planes * 4))
 
     def forward(self, x):

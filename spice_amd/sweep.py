@@ -30,6 +30,7 @@ from . import dist as sdist
 from . import ops
 from .engine import MagnitudeImportance, MagnitudePruner
 from .engine.pruner import SliceJob
+from .nets.layers import Conv1x1
 
 DEFAULT_RATIOS = (0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9)
 
@@ -144,6 +145,8 @@ class SensitivitySweep:
             key = (n, cin, h, w, cout, groups, mod.kernel_size, mod.stride, mod.padding, mod.dilation)
             if key in self._warmed or groups == cin:  # depthwise convolutions do not go through MIOpen
                 continue
+            if isinstance(mod, Conv1x1) and mod.takes_matrix_path(self.autocast_dtype or in_dtype):
+                continue  # a plain matrix product: no solver lookup to get out of the way
             self._warmed.add(key)
             dt = self.autocast_dtype or in_dtype
             x = torch.empty(n, cin, h, w, device=self.device, dtype=dt)

@@ -488,7 +488,7 @@ def test_model_forward_on_library_kernels_equals_torch_forward(dev):
     from one call to the next.)"""
     from spice_amd import nets
     from spice_amd.nets.decoders import BilinearLike, BilinearUp
-    from spice_amd.nets.layers import BatchNormAct2d
+    from spice_amd.nets.layers import BatchNormAct2d, Conv1x1, DepthwiseConv3x3
     torch.manual_seed(11)
     for arch in ("DeepLabV3Plus", "FPN", "Unet"):
         model = nets.create_model(arch, "resnet50", 5).to(dev).eval()
@@ -498,7 +498,8 @@ def test_model_forward_on_library_kernels_equals_torch_forward(dev):
                 m.running_var.uniform_(0.5, 1.5)
                 m.weight.data.uniform_(0.5, 1.5)
                 m.bias.data.normal_(0.0, 0.2)
-        watched = [m for m in model.modules() if isinstance(m, (BatchNormAct2d, BilinearUp, BilinearLike))]
+        watched = [m for m in model.modules()
+                   if isinstance(m, (BatchNormAct2d, BilinearUp, BilinearLike, Conv1x1, DepthwiseConv3x3))]
         x = torch.randn(2, 3, 128, 128, device=dev)
         for cast in (True, False):
             seen = []
@@ -514,7 +515,13 @@ def test_model_forward_on_library_kernels_equals_torch_forward(dev):
                     again = mod(*inputs).detach()   # gradient mode: the torch ops
                     if isinstance(mod, BatchNormAct2d) or getattr(mod, "follow_input_dtype", False) or isinstance(mod, BilinearLike):
                         again = again.to(out.dtype)  # torch up-samples to fp32 under autocast; the consumer casts back
-                    assert again.dtype == out.dtype and torch.equal(out, again), (arch, cast, type(mod).__name__)
+                    assert again.dtype == out.dtype, (arch, cast, type(mod).__name__)
+                    if isinstance(mod, (Conv1x1, DepthwiseConv3x3)):
+                        # another route to the same sums (fp32 accumulation either way): a few fp16 steps where terms cancel
+                        scale = float(again.float().abs().max())
+                        assert float((out.float() - again.float()).abs().max()) <= 4e-3 * scale, (arch, cast, type(mod).__name__)
+                    else:
+                        assert torch.equal(out, again), (arch, cast, type(mod).__name__)
 
 
 @pytest.mark.parametrize("shape,w_dtype", [((2, 6, 8, 8), torch.float16), ((1, 3, 5, 16), torch.float32),

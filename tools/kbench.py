@@ -194,6 +194,28 @@ def main():
             report(f"torch conv2d depthwise {shp}", timed(fns, args.iters), nbytes)
             outs.clear()
 
+    if want("bnact"):
+        # the largest batch-norms of DeepLabV3+-R50 at the benchmark geometry: layer1 [8,256,128,128] fp16,
+        # with and without the residual; torch's three kernels beside them
+        import torch.nn.functional as F
+        shp = (8, 256, 128, 128)
+        xs = [torch.randn(*shp, device=dev).half() for _ in range(3)]
+        rs = [torch.randn(*shp, device=dev).half() for _ in range(3)]
+        c = shp[1]
+        mean, var = torch.randn(c, device=dev), torch.rand(c, device=dev) + 0.5
+        wt, b = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev)
+        outs = []
+        keep = lambda t: outs.append(t) or (len(outs) > 2 and outs.pop(0))
+        nb = xs[0].numel() * 2
+        report("bn_act relu", timed([lambda a=a: keep(ops.bn_act(a, mean, var, wt, b, 1e-5, relu=True)) for a in xs], args.iters), 2 * nb)
+        report("torch batch_norm + relu", timed([lambda a=a: keep(F.relu(F.batch_norm(a, mean, var, wt, b, False, 0.0, 1e-5))) for a in xs],
+                                                args.iters), 2 * nb)
+        report("bn_act add relu", timed([lambda a=a, r=r: keep(ops.bn_act(a, mean, var, wt, b, 1e-5, residual=r, relu=True))
+                                         for a, r in zip(xs, rs)], args.iters), 3 * nb)
+        report("torch batch_norm + add + relu", timed([lambda a=a, r=r: keep(F.relu(F.batch_norm(a, mean, var, wt, b, False, 0.0, 1e-5) + r))
+                                                      for a, r in zip(xs, rs)], args.iters), 3 * nb)
+        outs.clear()
+
 
 if __name__ == "__main__":
     main()

@@ -287,6 +287,13 @@ int spice_bn_act(const void *x, const void *residual, void *y, int32_t dtype, co
 int spice_depthwise_conv3x3(const void *x, const void *weight, int32_t weight_dtype, void *y,
                             int64_t n, int64_t c, int32_t h, int32_t w, void *stream);
 
+/* The same with padding = dilation, dilation a multiple of 4 (the ASPP branches: 12 / 24 / 36).
+ * torch serves these calls with its own depthwise kernel, which sums the nine products in fp32 in
+ * tap order; this entry point does exactly that (bit-identical results). */
+int spice_depthwise_conv3x3_dilated(const void *x, const void *weight, int32_t weight_dtype, void *y,
+                                    int64_t n, int64_t c, int32_t h, int32_t w, int32_t dilation,
+                                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,10 +83,90 @@ __global__ __launch_bounds__(kDwThreads) void depthwise3x3_kernel(DwArgs a) {
     if (active) *reinterpret_cast<f16x8_t *>(a.y + (static_cast<int64_t>(plane) * a.h + y) * a.wd + x0) = out;
 }
 
+// Dilated variant (dilation a multiple of 4, padding = dilation): the three depthwise branches of the
+// ASPP block (dilation 12 / 24 / 36 on 32x32 planes).  torch runs these on its own depthwise kernel,
+// which accumulates the nine products in fp32 in tap order (row by row, left to right); so does this
+// one, with the same fused multiply-adds (a tap outside the plane contributes w * 0, which leaves the
+// sum as it is).  A lane's 8 outputs read, per tap, two groups of four consecutive inputs; with the
+// dilation and the width multiples of 4 a group lies entirely inside or entirely outside the plane.
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(kDwThreads) void depthwise3x3_dilated_kernel(DwArgs a, int dil) {
+    const int plane = blockIdx.x / a.blocks_per_plane;
+    const int band = blockIdx.x - plane * a.blocks_per_plane;
+    const int ch = plane % a.c;
+    const int ly = threadIdx.x / a.lanes_per_row;
+    const int lx = threadIdx.x - ly * a.lanes_per_row;
+    const int y = band * a.rows_per_block + ly;
+    const bool active = ly < a.rows_per_block && y < a.h;
+    const int yc = min(y, a.h - 1);
+    const int x0 = lx * 8;
+
+    float wt[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const _Float16 v = a.w_is_f32 ? static_cast<_Float16>(static_cast<const float *>(a.w)[ch * 9 + k])
+                                      : static_cast<const _Float16 *>(a.w)[ch * 9 + k];
+        wt[k] = static_cast<float>(v);
+    }
+    const _Float16 *src = a.x + static_cast<int64_t>(plane) * a.h * a.wd;
+    f16x4_t g[3][3][2];
+    bool ok[3][3][2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int yy = yc + (r - 1) * dil;
+        const bool row_in = yy >= 0 && yy < a.h;
+        const _Float16 *row = src + static_cast<int64_t>(min(max(yy, 0), a.h - 1)) * a.wd;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int s = x0 + (j - 1) * dil + 4 * k;
+                ok[r][j][k] = row_in && s >= 0 && s + 4 <= a.wd;
+                g[r][j][k] = *reinterpret_cast<const f16x4_t *>(row + min(max(s, 0), a.wd - 4));
+            }
+    }
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = ok[r][j][e >> 2] ? static_cast<float>(g[r][j][e >> 2][e & 3]) : 0.0f;
+                acc[e] = __builtin_fmaf(wt[r * 3 + j], v, acc[e]);
+            }
+    f16x8_t out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = acc[e];
+        asm volatile("" : "+v"(v));   // fp32 sum first, conversion as a step of its own
+        out[e] = static_cast<_Float16>(v);
+    }
+    if (active) *reinterpret_cast<f16x8_t *>(a.y + (static_cast<int64_t>(plane) * a.h + y) * a.wd + x0) = out;
+}
+
 }  // namespace spice
+
+static int spice_depthwise_common(const void *x, const void *weight, int32_t weight_dtype, void *y, int64_t n,
+                                  int64_t c, int32_t h, int32_t w, int32_t dilation, void *stream);
+
+extern "C" int spice_depthwise_conv3x3_dilated(const void *x, const void *weight, int32_t weight_dtype, void *y,
+                                               int64_t n, int64_t c, int32_t h, int32_t w, int32_t dilation,
+                                               void *stream) {
+    if (dilation < 4 || dilation % 4 != 0) return SPICE_ERR_UNSUPPORTED;
+    return spice_depthwise_common(x, weight, weight_dtype, y, n, c, h, w, dilation, stream);
+}
 
 extern "C" int spice_depthwise_conv3x3(const void *x, const void *weight, int32_t weight_dtype, void *y,
                                        int64_t n, int64_t c, int32_t h, int32_t w, void *stream) {
+    return spice_depthwise_common(x, weight, weight_dtype, y, n, c, h, w, 1, stream);
+}
+
+static int spice_depthwise_common(const void *x, const void *weight, int32_t weight_dtype, void *y, int64_t n,
+                                  int64_t c, int32_t h, int32_t w, int32_t dilation, void *stream) {
     using namespace spice;
     if (n < 0 || c <= 0 || h <= 0 || w <= 0) return SPICE_ERR_ARG;
     if (n == 0) return SPICE_OK;
@@ -108,8 +188,12 @@ extern "C" int spice_depthwise_conv3x3(const void *x, const void *weight, int32_
     a.w_is_f32 = weight_dtype == 0;
     const int64_t blocks = n * c * a.blocks_per_plane;
     if (blocks > INT32_MAX) return SPICE_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(depthwise3x3_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kDwThreads), 0,
-                       static_cast<hipStream_t>(stream), a);
+    if (dilation == 1)
+        hipLaunchKernelGGL(depthwise3x3_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kDwThreads), 0,
+                           static_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(depthwise3x3_dilated_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kDwThreads), 0,
+                           static_cast<hipStream_t>(stream), a, dilation);
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;
 }

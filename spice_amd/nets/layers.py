@@ -42,22 +42,25 @@ class BatchNormAct2d(nn.BatchNorm2d):
 
 
 class DepthwiseConv3x3(nn.Conv2d):
-    """nn.Conv2d(ch, ch, 3, padding=dilation, dilation=dilation, groups=ch, bias=False).  Without
-    dilation, on fp16 activations (autocast) under no_grad on a HIP device, the forward is the
-    library's streaming kernel (exact sums, one rounding: what MIOpen's reference kernel, which
-    serves these shapes, computes); in every other situation torch's conv2d runs."""
+    """nn.Conv2d(ch, ch, 3, padding=dilation, dilation=dilation, groups=ch, bias=False).  On fp16
+    activations (autocast) under no_grad on a HIP device, with dilation 1 or a multiple of 4, the
+    forward is the library's streaming kernel: exact sums and one rounding without dilation (what
+    MIOpen's reference kernel, which serves those shapes, computes), fp32 sums in tap order with
+    dilation (what torch's own depthwise kernel, which serves those, computes).  In every other
+    situation torch's conv2d runs."""
 
     def __init__(self, channels: int, dilation: int = 1):
         super().__init__(channels, channels, 3, padding=dilation, dilation=dilation, groups=channels, bias=False)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if (not torch.is_grad_enabled() and x.is_cuda and self.dilation == (1, 1) and self.stride == (1, 1)
-                and self.padding == (1, 1) and self.bias is None and self.groups == self.in_channels == self.out_channels
+        d = self.dilation[0]
+        if (not torch.is_grad_enabled() and x.is_cuda and (d == 1 or d % 4 == 0) and self.dilation == (d, d)
+                and self.stride == (1, 1) and self.padding == (d, d) and self.bias is None and self.groups == self.in_channels == self.out_channels
                 and (x.dtype == torch.float16 or torch.is_autocast_enabled("cuda"))):
             if x.dtype != torch.float16 and torch.get_autocast_dtype("cuda") == torch.float16:
                 x = x.to(torch.float16)   # what autocast does to a convolution's input
             if ops.depthwise_conv3x3_supported(x, self.weight):
-                return ops.depthwise_conv3x3(x, self.weight)
+                return ops.depthwise_conv3x3(x, self.weight, d)
         return super().forward(x)
 
 

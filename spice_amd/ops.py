@@ -493,8 +493,10 @@ def depthwise_conv3x3_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
             and tuple(weight.shape) == (x.shape[1], 1, 3, 3) and weight.is_contiguous())
 
 
-def depthwise_conv3x3(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
-    """conv2d(x, weight, stride=1, padding=1, groups=C) for fp16 x, exact sums, one rounding."""
+def depthwise_conv3x3(x: torch.Tensor, weight: torch.Tensor, dilation: int = 1) -> torch.Tensor:
+    """conv2d(x, weight, stride=1, padding=dilation, dilation=dilation, groups=C) for fp16 x.
+    dilation 1: exact sums, one rounding; dilation a multiple of 4: fp32 sums in tap order (what
+    torch's own depthwise kernel, which serves those calls, computes)."""
     nat.require_device_tensor(x, "x", torch.float16)
     if weight.dtype not in (torch.float16, torch.float32):
         raise TypeError(f"depthwise_conv3x3: weight dtype {weight.dtype} not supported")
@@ -503,7 +505,12 @@ def depthwise_conv3x3(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
         raise ValueError("depthwise_conv3x3: x must be [N,C,H,W] and weight [C,1,3,3]")
     n, c, h, w = x.shape
     out = torch.empty_like(x)
-    rc = nat.lib().spice_depthwise_conv3x3(x.data_ptr(), weight.data_ptr(), 0 if weight.dtype == torch.float32 else 1,
-                                           out.data_ptr(), n, c, h, w, _raw_stream(x.device.index))
+    code = 0 if weight.dtype == torch.float32 else 1
+    if dilation == 1:
+        rc = nat.lib().spice_depthwise_conv3x3(x.data_ptr(), weight.data_ptr(), code, out.data_ptr(), n, c, h, w,
+                                               _raw_stream(x.device.index))
+    else:
+        rc = nat.lib().spice_depthwise_conv3x3_dilated(x.data_ptr(), weight.data_ptr(), code, out.data_ptr(), n, c, h, w,
+                                                       int(dilation), _raw_stream(x.device.index))
     nat.check(rc, "spice_depthwise_conv3x3")
     return out

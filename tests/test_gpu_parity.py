@@ -556,3 +556,20 @@ def test_depthwise_conv3x3_rejects_other_layouts(dev):
         ops.depthwise_conv3x3(x.float(), w)
     with pytest.raises(ValueError):
         ops.depthwise_conv3x3(x[..., :8].contiguous(), w[:3])
+
+
+@pytest.mark.parametrize("shape,dilation", [((2, 16, 40, 48), 4), ((1, 8, 16, 24), 8), ((4, 2048, 32, 32), 12),
+                                             ((2, 512, 32, 32), 24), ((2, 512, 32, 32), 36), ((1, 3, 9, 8), 12)])
+def test_dilated_depthwise_conv3x3_vs_oracle_and_torch(dev, shape, dilation):
+    """Bit for bit against the oracle's fp32 tap-order sum and against torch's device result (its own
+    depthwise kernel serves dilated calls and sums the same way)."""
+    from oracle import depthwise as od
+    g = torch.Generator().manual_seed(sum(shape) + dilation)
+    x = torch.randn(*shape, generator=g).half()
+    w = (0.5 * torch.randn(shape[1], 1, 3, 3, generator=g))
+    got = ops.depthwise_conv3x3(x.to(dev), w.to(dev), dilation)
+    assert torch.equal(got.cpu(), od.depthwise_conv3x3_fp32_chain(x, w, dilation))
+    there = torch.nn.functional.conv2d(x.to(dev), w.to(dev).half(), None, 1, dilation, dilation, shape[1])
+    assert torch.equal(got, there)
+    with pytest.raises(RuntimeError):
+        ops.depthwise_conv3x3(x.to(dev), w.to(dev), 6)

@@ -21,7 +21,7 @@ def collect(directory, counter):
     for path in glob.glob(f"{directory}/**/*counter_collection.csv", recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
-                if row["Counter_Name"] == counter and "spice::" in row["Kernel_Name"]:
+                if row["Counter_Name"] == counter and "spice" in row["Kernel_Name"]:  # mangled names too (fp16 template arguments)
                     name = row["Kernel_Name"].replace("void ", "").split("(")[0]
                     out.setdefault(name, []).append(float(row["Counter_Value"]))
     return out

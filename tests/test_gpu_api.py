@@ -433,3 +433,23 @@ def test_run_eval_command_line_one_and_two_ranks(dev, tmp_path, capsys):
     run_eval.main(common + ["--output-dir", str(tmp_path / "two"), "--clear-cache", "--single-model", "FPN_resnet_taylor_0.20_kd"])
     out = capsys.readouterr().out
     assert "Evaluation cache cleared" in out and "Model: FPN_resnet_taylor_0.20_kd" in out
+
+
+def test_baseline_run_eval_prints_the_table(dev, tmp_path, capsys):
+    """baseline/eval/run_eval.py:31-115: models whose checkpoint exists are evaluated, the others
+    skipped; the table is printed in the reference's layout."""
+    from spice_amd.baseline.eval import run_eval
+    from spice_amd.baseline.eval.model_factory import get_model_by_name
+    torch.manual_seed(9)
+    for name in ("UNET_resnet", "FPN_resnet"):
+        model, rel = get_model_by_name(name)
+        (tmp_path / rel).parent.mkdir(parents=True)
+        torch.save(model.state_dict(), tmp_path / rel)
+    loader = [(torch.randn(2, 3, 64, 64), torch.randint(0, 5, (2, 64, 64))) for _ in range(2)]
+    results = run_eval.main(root=str(tmp_path), eval_loader=loader)
+    out = capsys.readouterr().out
+    assert [r["model"] for r in results] == ["UNET_resnet", "FPN_resnet"]
+    assert f"{'Model':<30} {'mIoU':<10} {'Mean Acc':<10}" in out
+    for r in results:
+        assert f"{r['model']:<30} {r['miou']:<10.4f} {r['mean_acc']:<10.4f}" in out
+        assert 0.0 <= r["miou"] <= 1.0 and len(r["per_class_iou"]) == 5

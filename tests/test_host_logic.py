@@ -204,3 +204,22 @@ def test_run_eval_parser_defaults_and_config(tmp_path, monkeypatch):
     with pytest.raises(SystemExit):
         run_eval.parse_args(["--device", "tpu"])
     run_eval.main(["--output-dir", str(tmp_path / "none"), "--no-eval", "--no-visualize", "--device", "cuda"])  # no CSV yet: message, no work
+
+
+def test_baseline_eval_configuration_matches_reference():
+    """baseline/eval/config.py:5-65 and model_factory.py:35-52: constants, the six entries, their
+    checkpoint paths, and the error for an unknown name."""
+    from spice_amd.baseline.eval import config as bc
+    from spice_amd.baseline.eval.model_factory import create_model_from_config, get_model_by_name
+    assert (bc.NUM_CLASSES, bc.IMG_SIZE, bc.BATCH_SIZE, bc.NUM_WORKERS) == (5, 576, 64, 16)
+    assert list(bc.MODEL_CONFIGS) == ["DeepLabV3Plus_resnet", "DeepLabV3Plus_efficientnet", "UNET_resnet", "UNET_efficientnet",
+                                      "FPN_resnet", "FPN_efficientnet"]
+    e = bc.MODEL_CONFIGS["UNET_efficientnet"]
+    assert e == {"architecture": "Unet", "encoder_name": "timm-efficientnet-b3", "encoder_weights": None, "in_channels": 3,
+                 "classes": 5, "activation": None, "checkpoint_path": "checkpoints/fullsize/UNET_efficientnet/UNET_efficientnet.pt"}
+    model, path = get_model_by_name("FPN_resnet")
+    assert path == "checkpoints/fullsize/FPN_resnet/FPN_resnet.pt" and hasattr(model, "segmentation_head")
+    with pytest.raises(ValueError, match="Unknown model"):
+        get_model_by_name("nope")
+    with pytest.raises(ValueError, match="Unknown architecture"):
+        create_model_from_config(dict(e, architecture="PSPNet"))

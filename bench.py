@@ -172,6 +172,21 @@ def kernel_table(dev):
     conf5 = torch.zeros(19, 19, dtype=torch.int64, device=dev)
     row("confusion [32,1024,2048] int64, 19 classes",
         event_ms(lambda: ops.confusion_update(conf5, p5, t5, 19), 10, batch=4), P5 * 16)
+    del t5, p5
+    # the forward-side kernels at the shapes they meet in this workload (results dropped at once: the caching
+    # allocator hands the same few output buffers round, the inputs rotate)
+    heads = [torch.randn(BATCH, CLASSES, SIZE // 4, SIZE // 4, device=dev).half() for _ in range(3)]
+    row("bilinear x4 up-sampling of the head, fp16 -> fp32 logits",
+        event_ms(lambda: ops.upsample_bilinear(cyc(heads), scale_factor=4.0, align_corners=True, out_dtype=torch.float32), 20),
+        heads[0].numel() * (2 + 16 * 4))
+    acts = [torch.randn(BATCH, 256, SIZE // 4, SIZE // 4, device=dev).half() for _ in range(4)]
+    bn = [torch.rand(256, device=dev) + 0.5 for _ in range(4)]
+    row("batch-norm + residual add + ReLU, [8,256,128,128] fp16",
+        event_ms(lambda: ops.bn_act(cyc(acts), bn[0], bn[1], bn[2], bn[3], 1e-5, residual=acts[k[0] % 4 - 1], relu=True), 20),
+        acts[0].numel() * 2 * 3)
+    wdw = torch.randn(256, 1, 3, 3, device=dev)
+    row("depthwise 3x3 (exact sums), [8,256,128,128] fp16",
+        event_ms(lambda: ops.depthwise_conv3x3(cyc(acts), wdw), 20), acts[0].numel() * 2 * 2)
     return out
 
 
@@ -314,7 +329,8 @@ def main():
                                "ratio) candidate per step = gather + forward + arg-max/confusion + KD-Lite loss",
                    "num_classes": CLASSES, "eval_batch": [BATCH, 3, SIZE, SIZE], "candidates": n_cand,
                    "groups": len(sweep.groups), "ratios": list(DEFAULT_RATIOS),
-                   "forward": "fp32" if args.fp32_forward else "fp16 autocast (MIOpen)",
+                   "forward": "fp32" if args.fp32_forward else ("fp16 autocast; convolutions on MIOpen / rocBLAS; up-sampling, batch-norm(+add+ReLU) "
+                                                                "and depthwise 3x3 on the library's kernels"),
                    "kd": {"T": 4.0, "alpha": 0.7}, "parallelism": f"candidates sharded over {world} rank(s)"},
         "roofline": {"bound": "hbm", "kernel": "spice::kdlite_main_kernel<4,false,false,false> (one launch per "
                      "spice_kdlite_forward call)", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS,

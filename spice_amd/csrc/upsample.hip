@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kUpThreads) void upsample_bilinear_kernel(UpArgs a)
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const float sx = src_index(a.scale_w, ox + e, a.align_corners);
-            const int x0 = static_cast<int>(sx);
+            const int x0 = min(static_cast<int>(sx), a.in_w - 1);   // never past the row, whatever the rounding of sx
             const int x1 = min(x0 + 1, a.in_w - 1);
             const float w1 = sx - static_cast<float>(x0);
             const float w0 = 1.0f - w1;
@@ -97,8 +97,8 @@ __global__ __launch_bounds__(kUpThreads) void upsample_bilinear_kernel(UpArgs a)
         const int ry = static_cast<int>((static_cast<float>(q) + 0.5f) * a.inv_per_row);
         const int ox = (q - ry * per_row) * VEC;
         const float sy = src_index(a.scale_h, oy0 + ry, a.align_corners);
-        const int y0 = static_cast<int>(sy);
-        const int y1 = min(y0 + 1, a.in_h - 1);
+        const int y0 = min(static_cast<int>(sy), y_hi);           // inside the rows staged above
+        const int y1 = min(y0 + 1, y_hi);
         const float h1 = sy - static_cast<float>(y0);
         const float h0 = 1.0f - h1;
         const float *r0 = hrows + (y0 - y_lo) * a.out_w + ox;

@@ -64,7 +64,9 @@ __global__ __launch_bounds__(kUpThreads) void upsample_bilinear_kernel(UpArgs a)
     // source rows of the band: from the upper row of its first output row to the lower row of its last
     const int y_lo = static_cast<int>(src_index(a.scale_h, oy0, a.align_corners));
     const int y_last = static_cast<int>(src_index(a.scale_h, oy0 + n_rows - 1, a.align_corners));
-    const int y_hi = min(y_last + 1, a.in_h - 1);
+    // the host sized the LDS tile for lds_rows rows, an upper bound of what a band touches; the clamp keeps a
+    // violated bound from becoming an out-of-range LDS access
+    const int y_hi = min(min(y_last + 1, a.in_h - 1), y_lo + a.lds_rows - 1);
     const int n_src_rows = y_hi - y_lo + 1;
     const TIn *sp = static_cast<const TIn *>(a.src) + (static_cast<int64_t>(plane) * a.in_h + y_lo) * a.in_w;
     const int per_row = a.out_w / VEC;

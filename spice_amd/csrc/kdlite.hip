@@ -663,12 +663,15 @@ static int device_cu_count() {
 // Workgroups of the loss kernel, each looping over its tiles.  Measured on MI355X (256 CUs): the
 // plain loss inside the sweep step 65.8 us with two per CU and 66.8 us with three (standalone on
 // cold inputs 65.8 / 64.1 us); with the boundary / confidence options, whose register use allows
-// exactly three resident workgroups per CU, 76.9 us with two and 70.1 us with three.
-static int kd_max_blocks(bool ext) {
+// exactly three resident workgroups per CU, 76.9 us with two and 70.1 us with three.  With few classes
+// a tile is short (48 bytes per pixel at 5 classes against 176 at 21) and more workgroups are needed
+// to keep as many bytes in flight: [32,5,576,576] takes 118 us with two per CU, 102 us with four.
+static int kd_max_blocks(bool ext, int64_t classes) {
     const char *e = getenv("SPICE_KD_MAX_BLOCKS");  // tuning knob (host side only)
     const int v = e ? atoi(e) : 0;
     if (v >= 1 && v <= kKdMaxBlocks) return v;
-    const int d = (ext ? 3 : 2) * device_cu_count();
+    const int per_cu = classes <= 8 ? 4 : (ext ? 3 : 2);
+    const int d = per_cu * device_cu_count();
     return d < kKdMaxBlocks ? d : kKdMaxBlocks;
 }
 
@@ -759,7 +762,7 @@ extern "C" int spice_kdlite_forward(const float *student, const float *teacher, 
     if (tiles > INT32_MAX) return SPICE_ERR_UNSUPPORTED;
     int64_t blocks = tiles;
     if (blocks < 1) blocks = 1;
-    if (blocks > kd_max_blocks(ext)) blocks = kd_max_blocks(ext);
+    if (blocks > kd_max_blocks(ext, c)) blocks = kd_max_blocks(ext, c);
 
     KdArgs a;
     a.s = student;

@@ -139,6 +139,27 @@ def main():
             report("kdlite_fwd_bwd (prepass+main+finalize, incl. grad alloc)", timed(fns, args.iters), P * (3 * c * 4 + 8))
         del sets
 
+    if want("kdlite5"):
+        # the reference's own default geometry: 5 classes, 576x576, batch 32 (pruning/config.py)
+        n, c, h, w = 32, 5, 576, 576
+        P = n * h * w
+        sets = []
+        for k in range(2):
+            s5 = 3.0 * torch.randn(n, c, h, w, device=dev)
+            lab5 = torch.randint(0, c, (n, h, w), device=dev)
+            lab5[torch.rand(n, h, w, device=dev) < 0.05] = 255
+            sets.append((s5, s5 + torch.randn_like(s5), lab5))
+        cw = torch.tensor([0.5, 1.0, 1.5, 2.0, 1.0], device=dev)
+        fns = [lambda a=a: ops.kdlite_forward(a[0], a[1], a[2], temperature=4.0, alpha=0.7, class_weight=cw) for a in sets]
+        report("kdlite_fwd C=5 [32,5,576,576]", timed(fns, args.iters), P * (2 * c * 4 + 8))
+        fns = [lambda a=a: ops.kdlite_forward(a[0], a[1], a[2], temperature=4.0, alpha=0.7, class_weight=cw, want_grad=True) for a in sets]
+        report("kdlite_fwd_bwd C=5 (incl. grad alloc)", timed(fns, args.iters), P * (3 * c * 4 + 8))
+        lg = [a[0] for a in sets]
+        conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
+        fns = [lambda a=a: ops.argmax_confusion_update(conf, a[0], a[2], c) for a in sets]
+        report("argmax_confusion fp32 C=5", timed(fns, args.iters), P * (c * 4 + 8))
+        del sets
+
     if want("confusion"):
         for (n, h, w, c, copies, tag) in ((8, 512, 512, 21, 10, "cfg1"), (32, 1024, 2048, 19, 1, "cfg5")):
             for kind in ("uniform", "blocky"):

@@ -286,14 +286,16 @@ struct PixStats {
 // Fold U class planes (c0..c0+U-1) into the running softmax statistics of VEC pixels.
 // FULL = all U classes exist; otherwise loads are clamped to the last class and the surplus
 // values replaced by a large negative fill (their exponentials are exactly zero).
+// sv / tv receive the raw logits of the step (the caller of the register-resident gradient pass
+// keeps them; everyone else passes scratch arrays).
 // STAGE: the raw logits are also parked in LDS (slot (2c+which)*threads + tid, touched by this
 // thread only) for the gradient pass.
 template <int VEC, int U, bool FULL, bool CONF, bool STAGE>
 __device__ __forceinline__ void kd_fold(PixStats<VEC> &st, const float *__restrict__ s_img,
                                         const float *__restrict__ t_img, long long HW, int r,
                                         int c0, int C, const int (&id)[VEC], float k2,
-                                        typename VecF<VEC>::type *stage) {
-    float sv[U][VEC], tv[U][VEC];
+                                        typename VecF<VEC>::type *stage, float (&sv)[U][VEC],
+                                        float (&tv)[U][VEC]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int cc = FULL ? c0 + u : min(c0 + u, C - 1);
@@ -400,6 +402,33 @@ __device__ __forceinline__ void kd_grad4(const PixStats<VEC> &st, const float *_
     }
 }
 
+// Gradient of up to eight class planes whose logits are still in registers (C <= 8: the whole
+// class axis of a lane's pixels was loaded in ONE kd_fold step): no second read, 16-byte stores.
+template <int VEC>
+__device__ __forceinline__ void kd_grad_regs(const PixStats<VEC> &st, const float (&sv)[8][VEC],
+                                             const float (&tv)[8][VEC], float *__restrict__ g_img,
+                                             long long HW, int r, int C, const int (&id)[VEC], float k2,
+                                             const float (&gce)[VEC], const float (&gkd)[VEC],
+                                             const float (&izs)[VEC], const float (&iz1)[VEC],
+                                             const float (&izt)[VEC]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        if (u >= C) break;
+        float gv[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float sc = sv[u][e] - st.ms[e];
+            const float tc = tv[u][e] - st.mt[e];
+            const float p1 = fast_exp2(sc * kLog2e) * iz1[e];
+            const float ps = fast_exp2(sc * k2) * izs[e];
+            const float pt = fast_exp2(tc * k2) * izt[e];
+            const float onehot = (u == id[e]) ? 1.f : 0.f;
+            gv[e] = gce[e] * (p1 - onehot) + gkd[e] * (ps - pt);
+        }
+        store_vec<VEC>(g_img + (long long)u * HW + r, gv);
+    }
+}
+
 // Run by ONE workgroup of kKdThreads threads: fixed-order fp64 sum of the per-workgroup partials,
 // then the scalar epilogue of PixelKDLoss / CrossEntropyLoss / KDLiteLoss.
 __device__ __forceinline__ void kd_finalize(const double *partial, int n_blocks, double *totals,
@@ -451,11 +480,12 @@ __device__ __forceinline__ void kd_finalize(const double *partial, int n_blocks,
 
 // STAGE (gradient only): the tile's logits are parked in dynamic LDS during the statistics pass
 // and the gradient pass reads them from there instead of from memory.
-template <int VEC, bool GRAD, bool EXT, bool STAGE>
-__global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
+// REGS (gradient only, C <= 8): one step covers the class axis, the logits stay in registers.
+template <int VEC, bool GRAD, bool EXT, bool STAGE, bool REGS>
+__device__ __forceinline__ void kd_main_body(const KdArgs &a) {
     extern __shared__ float4 stage_raw[];
     typename VecF<VEC>::type *stage = reinterpret_cast<typename VecF<VEC>::type *>(stage_raw);
-    constexpr int U = STAGE ? 8 : 4;  // class planes per step (loads in flight: 2U per lane)
+    constexpr int U = (STAGE || REGS) ? 8 : 4;  // class planes per step (loads in flight: 2U per lane)
     __shared__ double red[kKdThreads / 64][8];
     __shared__ double norm[4];
     const int tid = threadIdx.x;
@@ -509,16 +539,22 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
             st.ms[e] = st.mt[e] = kNegFill;
             st.zs[e] = st.z1[e] = st.zt[e] = st.zt1[e] = st.at[e] = st.sy[e] = 0.f;
         }
-        if (use_c) {
+        float sv[U][VEC], tv[U][VEC];   // the logits of a step; after the loops, with REGS, the whole class axis
+        if (REGS) {
+            if (use_c)
+                kd_fold<VEC, U, false, true, false>(st, s_img, t_img, a.HW, r, 0, C, id, k2, stage, sv, tv);
+            else
+                kd_fold<VEC, U, false, false, false>(st, s_img, t_img, a.HW, r, 0, C, id, k2, stage, sv, tv);
+        } else if (use_c) {
 #pragma unroll 1
             for (int c0 = 0; c0 < CU; c0 += U)
-                kd_fold<VEC, U, true, true, STAGE>(st, s_img, t_img, a.HW, r, c0, C, id, k2, stage);
-            if (CU < C) kd_fold<VEC, U, false, true, STAGE>(st, s_img, t_img, a.HW, r, CU, C, id, k2, stage);
+                kd_fold<VEC, U, true, true, STAGE>(st, s_img, t_img, a.HW, r, c0, C, id, k2, stage, sv, tv);
+            if (CU < C) kd_fold<VEC, U, false, true, STAGE>(st, s_img, t_img, a.HW, r, CU, C, id, k2, stage, sv, tv);
         } else {
 #pragma unroll 1
             for (int c0 = 0; c0 < CU; c0 += U)
-                kd_fold<VEC, U, true, false, STAGE>(st, s_img, t_img, a.HW, r, c0, C, id, k2, stage);
-            if (CU < C) kd_fold<VEC, U, false, false, STAGE>(st, s_img, t_img, a.HW, r, CU, C, id, k2, stage);
+                kd_fold<VEC, U, true, false, STAGE>(st, s_img, t_img, a.HW, r, c0, C, id, k2, stage, sv, tv);
+            if (CU < C) kd_fold<VEC, U, false, false, STAGE>(st, s_img, t_img, a.HW, r, CU, C, id, k2, stage, sv, tv);
         }
 
         float wy[VEC], wkd[VEC];
@@ -581,6 +617,10 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
                 izt[e] = 1.f / st.zt[e];
             }
             float *g_img = a.grad + (long long)n * C * a.HW;
+            if constexpr (REGS) {
+                kd_grad_regs<VEC>(st, sv, tv, g_img, a.HW, r, C, id, k2, gce, gkd, izs, iz1, izt);
+                continue;
+            }
 #pragma unroll 1
             for (int c0 = 0; c0 < C4; c0 += 4)
                 kd_grad4<VEC, true, STAGE>(st, s_img, t_img, g_img, a.HW, r, c0, C, id, k2, gce, gkd, izs, iz1, izt, stage);
@@ -627,6 +667,17 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
     if (!last_flag) return;
     kd_finalize(a.main_partial, (int)gridDim.x, a.totals, a.out3, a.T, a.alpha, a.bw, a.conf);
     if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int VEC, bool GRAD, bool EXT, bool STAGE>
+__global__ __launch_bounds__(kKdThreads) void kdlite_main_kernel(KdArgs a) {
+    kd_main_body<VEC, GRAD, EXT, STAGE, false>(a);
+}
+
+// Loss + gradient for C <= 8 with the logits of a lane's four pixels held in registers.
+template <bool EXT>
+__global__ __launch_bounds__(kKdThreads) void kdlite_grad_regs_kernel(KdArgs a) {
+    kd_main_body<4, true, EXT, false, true>(a);
 }
 
 __global__ __launch_bounds__(256) void scale_inplace_kernel(float *x, int64_t n, const float *scale) {
@@ -680,6 +731,11 @@ static int kd_stage_mode() {
     return e ? atoi(e) : 1;
 }
 
+static int kd_regs_mode() {
+    const char *e = getenv("SPICE_KD_REGS");  // tuning knob: 0 = never keep the logits in registers for the gradient
+    return e ? atoi(e) : 1;
+}
+
 template <int VEC>
 static int kd_launch(const KdArgs &a, bool grad, bool ext, int blocks, hipStream_t st) {
     const dim3 g(blocks), b(kKdThreads);
@@ -721,6 +777,22 @@ static int kd_launch_staged(const KdArgs &a, bool ext, bool vec4, int blocks, si
         hipLaunchKernelGGL((kdlite_main_kernel<1, true, true, true>), g, b, lds_bytes, st, a);
     else
         hipLaunchKernelGGL((kdlite_main_kernel<1, true, false, true>), g, b, lds_bytes, st, a);
+    SPICE_LAUNCH_CHECK();
+    return SPICE_OK;
+}
+
+// Gradient with the logits kept in registers (C <= 8, 16-byte layout): label pre-pass + one pass.
+static int kd_launch_regs(const KdArgs &a, bool ext, int blocks, hipStream_t st) {
+    const dim3 g(blocks), b(kKdThreads);
+    if (ext)
+        hipLaunchKernelGGL((kdlite_prepass_kernel<4, true>), dim3(a.pre_blocks), b, 0, st, a);
+    else
+        hipLaunchKernelGGL((kdlite_prepass_kernel<4, false>), dim3(a.pre_blocks), b, 0, st, a);
+    SPICE_LAUNCH_CHECK();
+    if (ext)
+        hipLaunchKernelGGL((kdlite_grad_regs_kernel<true>), g, b, 0, st, a);
+    else
+        hipLaunchKernelGGL((kdlite_grad_regs_kernel<false>), g, b, 0, st, a);
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;
 }
@@ -792,6 +864,7 @@ extern "C" int spice_kdlite_forward(const float *student, const float *teacher, 
     a.coef_kd = coef_kd;
     a.conf = params->confidence_weight != 0;
 
+    if (grad != nullptr && vec4 && c <= 8 && kd_regs_mode() != 0) return kd_launch_regs(a, ext, (int)blocks, st);
     const size_t stage_bytes = (size_t)c * 2 * kKdThreads * sizeof(float);
     if (grad != nullptr && kd_stage_mode() != 0 && stage_bytes <= kKdMaxStageBytes) {
         int64_t b1 = n * ceil_div(hw, kKdThreads);  // tiles at one pixel per lane

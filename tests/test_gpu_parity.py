@@ -191,10 +191,13 @@ def test_kdlite_config3_size(dev, variant):
 
 
 @pytest.mark.parametrize("c,hw,variant", [(24, (20, 28), "default"), (25, (20, 28), "default"), (40, (9, 13), "boundary_conf"),
-                                          (2, (7, 5), "default"), (24, (6, 10), "boundary_conf"), (1, (8, 8), "default")])
+                                          (2, (7, 5), "default"), (24, (6, 10), "boundary_conf"), (1, (8, 8), "default"),
+                                          (8, (12, 16), "default"), (8, (12, 16), "boundary_conf"), (9, (12, 16), "default"),
+                                          (5, (36, 36), "boundary_conf"), (3, (4, 4), "default"), (7, (10, 6), "default")])
 def test_kdlite_gradient_both_sides_of_the_lds_limit(dev, c, hw, variant):
-    """The gradient pass parks the logits in LDS up to 24 classes and re-reads them above that:
-    both variants against the op-sequence oracle, aligned and odd geometries, 1 and 2 classes."""
+    """The gradient pass keeps the logits in registers up to 8 classes (16-byte layouts), parks them in
+    LDS up to 24 and re-reads them above that: every variant against the op-sequence oracle, aligned
+    and odd geometries, 1 and 2 classes."""
     h, w = hw
     g = torch.Generator().manual_seed(100 + c)
     s = 3.0 * torch.randn(2, c, h, w, generator=g)
@@ -204,7 +207,8 @@ def test_kdlite_gradient_both_sides_of_the_lds_limit(dev, c, hw, variant):
     kw = dict(temperature=3.0, alpha=0.6)
     if variant != "default":
         kw.update(boundary_weight=2.5, confidence_weight=True)
-    out3, grad, _ = ops.kdlite_forward(s.to(dev), t.to(dev), lab.to(dev), want_grad=True, **kw)
+    cw = torch.tensor(ok.FIVE_CLASS_WEIGHTS).to(dev) if c == 5 else None   # the reference weights exactly five classes
+    out3, grad, _ = ops.kdlite_forward(s.to(dev), t.to(dev), lab.to(dev), want_grad=True, class_weight=cw, **kw)
     ref, g_ref = ok.kdlite_loss_and_grad(s, t, lab, num_classes=c, **kw)
     for k, key in enumerate(("total", "ce", "kd")):
         assert abs(out3[k].item() - ref[key].item()) <= REL * abs(ref[key].item()) + 1e-7, (key, out3[k].item(), ref[key].item())

@@ -14,7 +14,7 @@ build/%.o: spice_amd/csrc/%.hip spice_amd/csrc/common.h include/spice_amd.h
 
 $(LIB): $(OBJ)
 	@mkdir -p spice_amd/lib
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ) -lhipblaslt
 
 clean:
 	rm -rf build $(LIB)

@@ -34,6 +34,7 @@ extern "C" {
 #define SPICE_ERR_ARG 10001         /* null pointer, negative size, misaligned base */
 #define SPICE_ERR_UNSUPPORTED 10002 /* shape outside what the kernels implement */
 #define SPICE_ERR_WORKSPACE 10003   /* workspace smaller than *_workspace_bytes() */
+#define SPICE_ERR_BLAS 10004        /* a hipBLASLt call failed */
 
 /* ABI version the library was built with (compare with SPICE_ABI_VERSION). */
 int spice_abi_version(void);
@@ -293,6 +294,21 @@ int spice_depthwise_conv3x3(const void *x, const void *weight, int32_t weight_dt
 int spice_depthwise_conv3x3_dilated(const void *x, const void *weight, int32_t weight_dtype, void *y,
                                     int64_t n, int64_t c, int32_t h, int32_t w, int32_t dilation,
                                     void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * (8) 1x1 stride-1 convolution of fp16 NCHW activations, without bias:
+ *   y[n][Cout, HW] = weight[Cout, Cin] @ x[n][Cin, HW]   (fp32 accumulation).
+ *
+ * Replaces torch's conv2d call for the 1x1 convolutions of the same models
+ * (two of the three convolutions of every ResNet bottleneck, the ASPP and decoder
+ * projections) on the inference path.  A hipBLASLt matrix product whose
+ * descriptors and algorithm are prepared once per (n, Cin, HW, Cout) and kept for
+ * the life of the process; the first call on a device creates a hipBLASLt handle
+ * (the one place where the library holds state of its own).  Only algorithms that
+ * need no scratch memory are used.
+ * ------------------------------------------------------------------------- */
+int spice_conv1x1_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int64_t hw,
+                      int64_t cout, void *stream);
 
 #ifdef __cplusplus
 }

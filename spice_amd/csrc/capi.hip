@@ -13,6 +13,8 @@ extern "C" const char *spice_error_string(int code) {
             return "shape or option not supported by the gfx950 kernels";
         case SPICE_ERR_WORKSPACE:
             return "workspace smaller than the *_workspace_bytes() requirement";
+        case SPICE_ERR_BLAS:
+            return "a hipBLASLt call failed";
         default:
             return hipGetErrorString(static_cast<hipError_t>(code));
     }

@@ -83,10 +83,10 @@ def _fp16_matrix(weight: torch.Tensor) -> torch.Tensor:
 class Conv1x1(nn.Conv2d):
     """nn.Conv2d(in_ch, out_ch, 1, bias=False).  With stride 1 on fp16 activations (autocast) under
     no_grad on a HIP device the forward is the matrix product it is, W[Cout,Cin] @ X[n][Cin,HW],
-    through torch.bmm: the same hipBLASLt kernels MIOpen's 1x1 solver launches (identical results
-    where that solver is the one MIOpen picks) without MIOpen's per-call host work, which is what
-    bounds a forward of ~70 convolutions once the device work is short.  In every other situation
-    torch's conv2d runs."""
+    through the library's hipBLASLt entry point (descriptors and algorithm cached per problem size):
+    fp16 inputs, fp32 accumulation, as MIOpen's 1x1 solvers, without MIOpen's per-call host work
+    (5 us instead of 34 us), which is what bounds a forward of ~70 convolutions once the device work is
+    short.  In every other situation torch's conv2d runs."""
 
     def __init__(self, in_channels: int, out_channels: int, stride: int = 1):
         super().__init__(in_channels, out_channels, 1, stride=stride, bias=False)
@@ -101,6 +101,5 @@ class Conv1x1(nn.Conv2d):
             if x.dtype != torch.float16:
                 x = x.to(torch.float16)   # what autocast does to a convolution's input
             if x.is_contiguous():
-                n, c, h, w = x.shape
-                return torch.bmm(_fp16_matrix(self.weight).expand(n, -1, -1), x.view(n, c, h * w)).view(n, -1, h, w)
+                return ops.conv1x1_f16(x, _fp16_matrix(self.weight))
         return super().forward(x)

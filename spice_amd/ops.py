@@ -514,3 +514,32 @@ def depthwise_conv3x3(x: torch.Tensor, weight: torch.Tensor, dilation: int = 1) 
                                                        int(dilation), _raw_stream(x.device.index))
     nat.check(rc, "spice_depthwise_conv3x3")
     return out
+
+
+_conv1x1_fn = None
+
+
+def conv1x1_f16(x: torch.Tensor, weight2d: torch.Tensor) -> torch.Tensor:
+    """weight2d[Cout, Cin] @ x[n][Cin, H*W] for fp16 NCHW x: a 1x1 stride-1 convolution without bias.
+    hipBLASLt with descriptors and algorithm cached per problem size; where hipBLASLt offers no
+    scratch-free algorithm for a size the product goes through torch.bmm (rocBLAS)."""
+    global _conv1x1_fn
+    if _conv1x1_fn is None:
+        _conv1x1_fn = nat.lib().spice_conv1x1_f16
+    if x.dtype != torch.float16 or weight2d.dtype != torch.float16:
+        raise TypeError("conv1x1_f16: x and weight must be fp16")
+    if not x.is_cuda or weight2d.device != x.device:
+        nat.require_device_tensor(x, "x", torch.float16)
+        raise RuntimeError("conv1x1_f16: weight must be on x's device")
+    if x.dim() != 4 or weight2d.dim() != 2 or weight2d.shape[1] != x.shape[1] or not x.is_contiguous() \
+            or not weight2d.is_contiguous():
+        raise ValueError("conv1x1_f16: x must be contiguous [N,Cin,H,W] and weight contiguous [Cout,Cin]")
+    n, cin, h, w = x.shape
+    cout = weight2d.shape[0]
+    out = torch.empty((n, cout, h, w), dtype=torch.float16, device=x.device)
+    rc = _conv1x1_fn(x.data_ptr(), weight2d.data_ptr(), out.data_ptr(), n, cin, h * w, cout, _raw_stream(x.device.index))
+    if rc == nat.ERR_UNSUPPORTED:
+        return torch.bmm(weight2d.expand(n, -1, -1), x.view(n, cin, h * w)).view(n, cout, h, w)
+    if rc:
+        nat.check(rc, "spice_conv1x1_f16")
+    return out

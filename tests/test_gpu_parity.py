@@ -577,3 +577,34 @@ def test_dilated_depthwise_conv3x3_vs_oracle_and_torch(dev, shape, dilation):
     assert torch.equal(got, there)
     with pytest.raises(RuntimeError):
         ops.depthwise_conv3x3(x.to(dev), w.to(dev), 6)
+
+
+@pytest.mark.parametrize("shape,cout", [((2, 64, 16, 16), 256), ((8, 256, 128, 128), 64), ((3, 230, 9, 7), 1000), ((1, 3, 5, 5), 7),
+                                         ((2, 2048, 32, 32), 512), ((2, 100, 1, 1), 33)])
+def test_conv1x1_f16_vs_oracle_and_torch(dev, shape, cout):
+    """The 1x1 convolution as a matrix product: against fp64 sums of the fp16 values (one fp16 step where
+    terms cancel) and against torch's conv2d on the device (fp32 accumulation as well, other kernel)."""
+    g = torch.Generator().manual_seed(sum(shape) + cout)
+    x = torch.randn(*shape, generator=g).half()
+    w = (torch.randn(cout, shape[1], generator=g) / shape[1] ** 0.5).half()
+    got = ops.conv1x1_f16(x.to(dev), w.to(dev))
+    exact = torch.einsum("oc,nchw->nohw", w.double(), x.double())
+    scale = float(exact.abs().max())
+    assert got.dtype == torch.float16 and got.shape == exact.shape
+    assert float((got.double().cpu() - exact).abs().max()) <= 2.0 ** -10 * scale + 1e-6
+    there = torch.nn.functional.conv2d(x.to(dev), w.to(dev).view(cout, shape[1], 1, 1))
+    assert float((got.float() - there.float()).abs().max()) <= 2.0 ** -9 * scale + 1e-6
+    again = ops.conv1x1_f16(x.to(dev), w.to(dev))     # the cached plan
+    assert torch.equal(got, again)
+
+
+def test_conv1x1_f16_rejects_other_layouts(dev):
+    x = torch.randn(1, 4, 3, 3, device=dev).half()
+    w = torch.randn(5, 4, device=dev).half()
+    with pytest.raises(TypeError):
+        ops.conv1x1_f16(x.float(), w)
+    with pytest.raises(ValueError):
+        ops.conv1x1_f16(x, w[:, :3].contiguous())
+    with pytest.raises(RuntimeError):
+        ops.conv1x1_f16(x.cpu(), w.cpu())
+    assert ops.conv1x1_f16(x[:0], w).shape == (0, 5, 3, 3)

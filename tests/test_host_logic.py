@@ -223,3 +223,60 @@ def test_baseline_eval_configuration_matches_reference():
         get_model_by_name("nope")
     with pytest.raises(ValueError, match="Unknown architecture"):
         create_model_from_config(dict(e, architecture="PSPNet"))
+
+
+def test_fused_modules_keep_torch_semantics_and_channel_coupling():
+    """The inference modules of the model zoo on their torch path (CPU): BatchNormAct2d == batch-norm, add,
+    ReLU; Conv1x1 / DepthwiseConv3x3 == conv2d; BilinearUp == UpsamplingBilinear2d; and the dependency
+    graph couples the channels of a residual block the same way whether the add is written out or sits
+    inside the batch-norm module."""
+    import torch.nn.functional as F
+    from spice_amd.nets.decoders import BilinearUp
+    from spice_amd.nets.layers import BatchNormAct2d, Conv1x1, DepthwiseConv3x3
+    torch.manual_seed(0)
+    x, r = torch.randn(2, 6, 5, 7), torch.randn(2, 6, 5, 7)
+    bn = BatchNormAct2d(6, relu=True).eval()
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_()
+    plain = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+    assert torch.equal(bn(x, r), F.relu(plain + r)) and torch.equal(bn(x), F.relu(plain))
+    assert torch.equal(BatchNormAct2d(6).eval()(x), F.batch_norm(x, torch.zeros(6), torch.ones(6), torch.ones(6), torch.zeros(6), False, 0.0, 1e-5))
+    c1 = Conv1x1(6, 4)
+    assert torch.equal(c1(x), F.conv2d(x, c1.weight)) and c1.takes_matrix_path(torch.float16) and not c1.takes_matrix_path(torch.float32)
+    assert not Conv1x1(6, 4, stride=2).takes_matrix_path(torch.float16)
+    dw = DepthwiseConv3x3(6, dilation=4)
+    assert torch.equal(dw(x), F.conv2d(x, dw.weight, None, 1, 4, 4, 6))
+    assert torch.equal(BilinearUp(2)(x), nn.UpsamplingBilinear2d(scale_factor=2)(x))
+
+    class Written(nn.Module):   # the residual add written out, stock modules
+        def __init__(self):
+            super().__init__()
+            self.stem = nn.Conv2d(3, 8, 3, padding=1)
+            self.c1, self.b1 = nn.Conv2d(8, 4, 1, bias=False), nn.BatchNorm2d(4)
+            self.c2, self.b2 = nn.Conv2d(4, 8, 1, bias=False), nn.BatchNorm2d(8)
+            self.head = nn.Conv2d(8, 2, 1)
+
+        def forward(self, x):
+            s = self.stem(x)
+            y = self.b2(self.c2(torch.relu(self.b1(self.c1(s)))))
+            return self.head(torch.relu(y + s))
+
+    class Folded(nn.Module):    # the same block with the model zoo's modules
+        def __init__(self):
+            super().__init__()
+            self.stem = nn.Conv2d(3, 8, 3, padding=1)
+            self.c1, self.b1 = Conv1x1(8, 4), BatchNormAct2d(4, relu=True)
+            self.c2, self.b2 = Conv1x1(4, 8), BatchNormAct2d(8, relu=True)
+            self.head = nn.Conv2d(8, 2, 1)
+
+        def forward(self, x):
+            s = self.stem(x)
+            return self.head(self.b2(self.c2(self.b1(self.c1(s))), s))
+
+    def shape(model):
+        return sorted((g.size, g.frozen, sorted((m.name, m.kind) for m in g.members)) for g in build_groups(model))
+
+    assert shape(Written()) == shape(Folded())
+    w, f = Written().eval(), Folded().eval()
+    f.load_state_dict(w.state_dict())
+    img = torch.randn(1, 3, 6, 6)
+    assert torch.equal(w(img), f(img))

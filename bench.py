@@ -239,7 +239,13 @@ def main():
     ap.add_argument("--warm-mode", default="upfront", choices=["upfront", "none"],
                     help="how the solver lookups for new convolution shapes are taken out of the candidate loop")
     ap.add_argument("--no-tune", action="store_true", help="skip the MIOpen find-database warm-up of the backbone")
+    ap.add_argument("--torch-forward", action="store_true",
+                    help="A/B: keep the models' up-sampling, batch-norm, depthwise and 1x1 modules on their torch path")
     args = ap.parse_args()
+    if args.torch_forward:
+        from spice_amd.nets import layers
+        layers.set_library_forward(False)
+        os.environ["SPICE_TORCH_FORWARD"] = "1"   # for the tuning child, which then tunes the 1x1 convolutions too
 
     # Set-up, before this process touches the GPU: a child process searches MIOpen solvers for the
     # un-pruned backbone's convolution shapes once and leaves them in this rank's find database.
@@ -329,8 +335,10 @@ def main():
                                "ratio) candidate per step = gather + forward + arg-max/confusion + KD-Lite loss",
                    "num_classes": CLASSES, "eval_batch": [BATCH, 3, SIZE, SIZE], "candidates": n_cand,
                    "groups": len(sweep.groups), "ratios": list(DEFAULT_RATIOS),
-                   "forward": "fp32" if args.fp32_forward else ("fp16 autocast; convolutions on MIOpen / rocBLAS; up-sampling, batch-norm(+add+ReLU) "
-                                                                "and depthwise 3x3 on the library's kernels"),
+                   "forward": "fp32" if args.fp32_forward else (
+                       "fp16 autocast, every module on torch's kernels (A/B run)" if args.torch_forward else
+                       "fp16 autocast; 3x3 convolutions on MIOpen, 1x1 on hipBLASLt; up-sampling, batch-norm(+add+ReLU) and "
+                       "depthwise 3x3 on the library's kernels"),
                    "kd": {"T": 4.0, "alpha": 0.7}, "parallelism": f"candidates sharded over {world} rank(s)"},
         "roofline": {"bound": "hbm", "kernel": "spice::kdlite_main_kernel<4,false,false,false> (one launch per "
                      "spice_kdlite_forward call)", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS,

@@ -33,7 +33,9 @@ def ensure_tuned(arch: str, encoder: str, classes: int, batch: int, size: int, a
     in the database directory makes repeated calls for the same problem free."""
     db = os.environ.setdefault("MIOPEN_USER_DB_PATH", default_db_dir(device))
     os.makedirs(db, exist_ok=True)
-    stamp = os.path.join(db, f"tuned_{arch}_{encoder}_{classes}_{batch}_{size}_{autocast}.stamp")
+    # the convolutions that reach MIOpen differ with SPICE_TORCH_FORWARD (the child inherits it): one stamp each
+    route = "torch" if os.environ.get("SPICE_TORCH_FORWARD", "0") == "1" else "lib"
+    stamp = os.path.join(db, f"tuned_{arch}_{encoder}_{classes}_{batch}_{size}_{autocast}_{route}.stamp")
     if os.path.exists(stamp):
         return 0.0
     env = dict(os.environ, MIOPEN_FIND_MODE="NORMAL", MIOPEN_USER_DB_PATH=db)

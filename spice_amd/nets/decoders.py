@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import layers
 from .layers import BatchNormAct2d, Conv1x1, DepthwiseConv3x3
 
 
@@ -37,7 +38,10 @@ class BilinearUp(nn.UpsamplingBilinear2d):
 
     def forward(self, x):
         wants_grad = torch.is_grad_enabled() and x.requires_grad
-        if not x.is_cuda or wants_grad or x.dim() != 4 or x.dtype not in (torch.float32, torch.float16):
+        # fp16 input is taken under autocast only, where torch would first cast it to fp32: torch's own fp16
+        # kernel rounds its last multiply-add and the conversion in one step, which differs on ties
+        if (not layers.library_forward() or not x.is_cuda or wants_grad or x.dim() != 4
+                or not (x.dtype == torch.float32 or (x.dtype == torch.float16 and torch.is_autocast_enabled("cuda")))):
             return super().forward(x)
         from .. import ops
         out_dtype = x.dtype
@@ -59,7 +63,8 @@ class BilinearLike(nn.Upsample):
     def forward(self, y, like):
         size = tuple(like.shape[-2:])
         wants_grad = torch.is_grad_enabled() and y.requires_grad
-        if not y.is_cuda or wants_grad or y.dim() != 4 or y.dtype not in (torch.float32, torch.float16):
+        if (not layers.library_forward() or not y.is_cuda or wants_grad or y.dim() != 4
+                or not (y.dtype == torch.float32 or (y.dtype == torch.float16 and torch.is_autocast_enabled("cuda")))):
             return F.interpolate(y, size=size, mode="bilinear", align_corners=False)
         from .. import ops
         return ops.upsample_bilinear(y.contiguous(), size=size, align_corners=False)

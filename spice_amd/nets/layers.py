@@ -2,6 +2,7 @@
 is a launch of the library instead of a chain of torch kernels."""
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Optional
 
@@ -10,6 +11,19 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+
+# SPICE_TORCH_FORWARD=1 keeps every module below (and the up-sampling modules of the decoders) on its
+# torch path, for A/B measurements of the library's forward-side kernels.
+_LIBRARY_FORWARD = os.environ.get("SPICE_TORCH_FORWARD", "0") != "1"
+
+
+def library_forward() -> bool:
+    return _LIBRARY_FORWARD
+
+
+def set_library_forward(enabled: bool) -> None:
+    global _LIBRARY_FORWARD
+    _LIBRARY_FORWARD = bool(enabled)
 
 
 class BatchNormAct2d(nn.BatchNorm2d):
@@ -27,7 +41,7 @@ class BatchNormAct2d(nn.BatchNorm2d):
         self.relu_after = relu
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if not (self.training or torch.is_grad_enabled()) and x.is_cuda and self.track_running_stats and self.affine:
+        if _LIBRARY_FORWARD and not (self.training or torch.is_grad_enabled()) and x.is_cuda and self.track_running_stats and self.affine:
             if ops.bn_act_supported(x) and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape
                                                                   and residual.is_contiguous())):
                 return ops.bn_act(x, self.running_mean, self.running_var, self.weight, self.bias, self.eps,
@@ -54,7 +68,7 @@ class DepthwiseConv3x3(nn.Conv2d):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         d = self.dilation[0]
-        if (not torch.is_grad_enabled() and x.is_cuda and (d == 1 or d % 4 == 0) and self.dilation == (d, d)
+        if (_LIBRARY_FORWARD and not torch.is_grad_enabled() and x.is_cuda and (d == 1 or d % 4 == 0) and self.dilation == (d, d)
                 and self.stride == (1, 1) and self.padding == (d, d) and self.bias is None and self.groups == self.in_channels == self.out_channels
                 and (x.dtype == torch.float16 or torch.is_autocast_enabled("cuda"))):
             if x.dtype != torch.float16 and torch.get_autocast_dtype("cuda") == torch.float16:
@@ -92,12 +106,12 @@ class Conv1x1(nn.Conv2d):
         super().__init__(in_channels, out_channels, 1, stride=stride, bias=False)
 
     def takes_matrix_path(self, x_dtype: torch.dtype) -> bool:
-        return (self.stride == (1, 1) and self.bias is None and self.groups == 1 and self.padding == (0, 0)
+        return (_LIBRARY_FORWARD and self.stride == (1, 1) and self.bias is None and self.groups == 1 and self.padding == (0, 0)
                 and (x_dtype == torch.float16 or
                      (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16)))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and self.takes_matrix_path(x.dtype):
+        if _LIBRARY_FORWARD and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and self.takes_matrix_path(x.dtype):
             if x.dtype != torch.float16:
                 x = x.to(torch.float16)   # what autocast does to a convolution's input
             if x.is_contiguous():

@@ -608,3 +608,26 @@ def test_conv1x1_f16_rejects_other_layouts(dev):
     with pytest.raises(RuntimeError):
         ops.conv1x1_f16(x.cpu(), w.cpu())
     assert ops.conv1x1_f16(x[:0], w).shape == (0, 5, 3, 3)
+
+
+def test_torch_forward_switch(dev):
+    """set_library_forward(False) keeps the modules on torch's kernels under no_grad as well; the
+    bit-identical ones (batch-norm, up-sampling, dilated depthwise) give the same tensors either way."""
+    from spice_amd.nets import layers
+    from spice_amd.nets.decoders import BilinearUp
+    torch.manual_seed(2)
+    x = torch.randn(2, 16, 12, 16, device=dev).half()
+    bn = layers.BatchNormAct2d(16, relu=True).to(dev).eval()
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    up, dw = BilinearUp(4), layers.DepthwiseConv3x3(16, dilation=4).to(dev).half()
+    assert layers.library_forward()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):   # as the sweep and the evaluation loops run
+        lib = (bn(x, x), up(x), dw(x))
+        layers.set_library_forward(False)
+        try:
+            assert not layers.Conv1x1(16, 8).takes_matrix_path(torch.float16)
+            ref = (bn(x, x), up(x), dw(x))
+        finally:
+            layers.set_library_forward(True)
+    for a, b in zip(lib, ref):
+        assert a.dtype == b.dtype and torch.equal(a, b)

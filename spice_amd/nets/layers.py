@@ -41,7 +41,8 @@ class BatchNormAct2d(nn.BatchNorm2d):
         self.relu_after = relu
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if _LIBRARY_FORWARD and not (self.training or torch.is_grad_enabled()) and x.is_cuda and self.track_running_stats and self.affine:
+        if _LIBRARY_FORWARD and not (self.training or torch.is_grad_enabled()) and x.is_cuda and self.track_running_stats and self.affine \
+                and self.weight.dtype == torch.float32 and self.running_mean.dtype == torch.float32:
             if ops.bn_act_supported(x) and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape
                                                                   and residual.is_contiguous())):
                 return ops.bn_act(x, self.running_mean, self.running_var, self.weight, self.bias, self.eps,

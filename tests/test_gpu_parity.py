@@ -631,3 +631,66 @@ def test_torch_forward_switch(dev):
             layers.set_library_forward(True)
     for a, b in zip(lib, ref):
         assert a.dtype == b.dtype and torch.equal(a, b)
+
+
+def test_half_precision_model_runs_through_the_modules(dev):
+    """model.half() (no autocast): batch-norm parameters are fp16 there, which the fused kernel does not
+    take - the modules must fall back to torch's ops instead of raising."""
+    from spice_amd import nets
+    torch.manual_seed(4)
+    model = nets.create_model("DeepLabV3Plus", "resnet50", 5).to(dev).eval().half()
+    with torch.no_grad():
+        y = model(torch.randn(1, 3, 64, 64, device=dev).half())
+    assert y.shape == (1, 5, 64, 64) and y.dtype == torch.float16 and bool(torch.isfinite(y).all())
+
+
+BN_CASES = [
+    # shape, dtype, residual, relu
+    ((2, 16, 8, 8), torch.float32, False, False),
+    ((2, 16, 8, 8), torch.float32, True, True),
+    ((3, 7, 5, 3), torch.float32, True, True),        # odd plane, scalar path
+    ((2, 24, 6, 6), torch.float16, False, True),      # planes of 36: vectors straddle planes
+    ((2, 24, 6, 6), torch.float16, True, True),
+    ((4, 10, 3, 2), torch.float16, True, False),      # planes shorter than a vector
+    ((8, 64, 36, 36), torch.float16, True, True),
+    ((8, 256, 64, 64), torch.float16, False, True),
+    ((1, 5, 1, 2), torch.float16, False, True),
+]
+
+
+@pytest.mark.parametrize("shape,dtype,with_res,relu", BN_CASES)
+def test_bn_act_vs_oracle_and_torch(dev, shape, dtype, with_res, relu):
+    """The fused kernel against the CPU oracle (one rounding step of the dtype at most) and against
+    the three device kernels it replaces (MIOpen batch-norm, add, clamp): bit for bit."""
+    from oracle import bnact as ob
+    g = torch.Generator().manual_seed(sum(shape))
+    c = shape[1]
+    x = (2.0 * torch.randn(*shape, generator=g)).to(dtype)
+    res = (2.0 * torch.randn(*shape, generator=g)).to(dtype) if with_res else None
+    mean, var = torch.randn(c, generator=g), torch.rand(c, generator=g) * 2 + 0.05
+    weight, bias = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    d = lambda t: None if t is None else t.to(dev)
+    got = ops.bn_act(d(x), d(mean), d(var), d(weight), d(bias), 1e-5, residual=d(res), relu=relu)
+    want = ob.bn_act(x, mean, var, weight, bias, 1e-5, residual=res, relu=relu)
+    assert got.dtype == dtype and got.shape == want.shape
+    step = 2e-3 if dtype == torch.float16 else 2e-6
+    assert float((got.float().cpu() - want.float()).abs().max()) <= step * max(1.0, float(want.float().abs().max()))
+    there = torch.nn.functional.batch_norm(d(x), d(mean), d(var), d(weight), d(bias), False, 0.0, 1e-5)
+    if with_res:
+        there = there + d(res)
+    if relu:
+        there = torch.relu(there)
+    assert torch.equal(got, there)
+
+
+def test_bn_act_rejects_what_it_does_not_reproduce(dev):
+    x = torch.randn(2, 4, 3, 3, device=dev).half()
+    p = [torch.ones(4, device=dev) for _ in range(4)]
+    assert not ops.bn_act_supported(x) and ops.bn_act_supported(x.float()) and ops.bn_act_supported(x[:, :, :, :2].contiguous())
+    with pytest.raises(RuntimeError):
+        ops.bn_act(x, *p, 1e-5)                      # fp16 with an odd plane size
+    with pytest.raises(ValueError):
+        ops.bn_act(x.float(), *p, 1e-5, residual=torch.zeros(2, 4, 3, 2, device=dev))
+    with pytest.raises(TypeError):
+        ops.bn_act(x.float(), p[0].half(), *p[1:], 1e-5)
+    assert ops.bn_act(x.float()[:0], *p, 1e-5).shape == (0, 4, 3, 3)

@@ -41,8 +41,9 @@ class BatchNormAct2d(nn.BatchNorm2d):
         self.relu_after = relu
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if _LIBRARY_FORWARD and not (self.training or torch.is_grad_enabled()) and x.is_cuda and self.track_running_stats and self.affine \
-                and self.weight.dtype == torch.float32 and self.running_mean.dtype == torch.float32:
+        inference = _LIBRARY_FORWARD and not (self.training or torch.is_grad_enabled()) and x.is_cuda
+        if (inference and self.track_running_stats and self.affine and self.weight.dtype == torch.float32
+                and self.running_mean.dtype == torch.float32):
             if ops.bn_act_supported(x) and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape
                                                                   and residual.is_contiguous())):
                 return ops.bn_act(x, self.running_mean, self.running_var, self.weight, self.bias, self.eps,
@@ -69,8 +70,9 @@ class DepthwiseConv3x3(nn.Conv2d):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         d = self.dilation[0]
-        if (_LIBRARY_FORWARD and not torch.is_grad_enabled() and x.is_cuda and (d == 1 or d % 4 == 0) and self.dilation == (d, d)
-                and self.stride == (1, 1) and self.padding == (d, d) and self.bias is None and self.groups == self.in_channels == self.out_channels
+        plain = (self.dilation == (d, d) and self.padding == (d, d) and self.stride == (1, 1) and self.bias is None
+                 and self.groups == self.in_channels == self.out_channels)
+        if (_LIBRARY_FORWARD and not torch.is_grad_enabled() and x.is_cuda and (d == 1 or d % 4 == 0) and plain
                 and (x.dtype == torch.float16 or torch.is_autocast_enabled("cuda"))):
             if x.dtype != torch.float16 and torch.get_autocast_dtype("cuda") == torch.float16:
                 x = x.to(torch.float16)   # what autocast does to a convolution's input
@@ -107,12 +109,13 @@ class Conv1x1(nn.Conv2d):
         super().__init__(in_channels, out_channels, 1, stride=stride, bias=False)
 
     def takes_matrix_path(self, x_dtype: torch.dtype) -> bool:
-        return (_LIBRARY_FORWARD and self.stride == (1, 1) and self.bias is None and self.groups == 1 and self.padding == (0, 0)
+        return (_LIBRARY_FORWARD and self.stride == (1, 1) and self.bias is None and self.groups == 1
+                and self.padding == (0, 0)
                 and (x_dtype == torch.float16 or
                      (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16)))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if _LIBRARY_FORWARD and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and self.takes_matrix_path(x.dtype):
+        if not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and self.takes_matrix_path(x.dtype):
             if x.dtype != torch.float16:
                 x = x.to(torch.float16)   # what autocast does to a convolution's input
             if x.is_contiguous():

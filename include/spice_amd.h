@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPICE_ABI_VERSION 1
+#define SPICE_ABI_VERSION 2
 
 #define SPICE_OK 0
 #define SPICE_ERR_ARG 10001         /* null pointer, negative size, misaligned base */
@@ -179,10 +179,13 @@ int spice_scale_inplace(float *x, int64_t n, const float *scale, void *stream);
  * ------------------------------------------------------------------------- */
 size_t spice_confusion_workspace_bytes(int64_t n_pixels, int32_t num_classes);
 
-/* conf: device [C,C] int64, updated in place.  The workspace's first int64 is
- * incremented by the number of pixels with a valid target but a prediction
- * outside [0,C) (the reference fails on those); they are not counted in conf.
- * The caller zeroes that word once after allocating the workspace. */
+/* conf: device [C,C] int64, updated in place, by ONE kernel launch.  The workspace's
+ * first int64 is incremented by the number of pixels with a valid target but a
+ * prediction outside [0,C) (the reference fails on those); they are not counted in
+ * conf.  The caller zeroes the first 4096 bytes of the workspace once after allocating
+ * it (they hold that count and arrival counters which every call returns to zero) and
+ * must not share one workspace between calls that may overlap in time.
+ * At most 2^40 pixels per call. */
 int spice_confusion_update(const int64_t *preds, const int64_t *target, int64_t n_pixels,
                            int32_t num_classes, int64_t *conf, void *workspace,
                            size_t workspace_bytes, void *stream);

@@ -16,8 +16,8 @@ import torch  # noqa: F401  (must precede the CDLL below)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libspice_amd.so")
 
-ABI_VERSION = 1
-ERR_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE = 10001, 10002, 10003
+ABI_VERSION = 2
+ERR_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_BLAS = 10001, 10002, 10003, 10004
 IMP_L1, IMP_L2, IMP_TAYLOR = 0, 1, 2
 
 

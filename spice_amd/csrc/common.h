@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/spice_amd.h"
 
@@ -25,6 +26,30 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 static inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Defines `static long fn()` returning the integer value of environment variable `name` (`unset`
+// when it is absent), read once per process: tuning knobs must not cost a getenv() per launch.
+#define SPICE_ENV_KNOB(fn, name, unset)              \
+    static long fn() {                               \
+        static const long v = [] {                   \
+            const char *e = getenv(name);            \
+            return e ? atol(e) : (long)(unset);      \
+        }();                                         \
+        return v;                                    \
+    }
+
+// Compute units of the current device (256 on MI355X), looked up once per device.
+static inline int device_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
 
 // Butterfly sum over the `width` lanes (power of two, <= 64) that share the
 // caller's aligned lane group; every lane of the group ends with the total.

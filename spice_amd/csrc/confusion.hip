@@ -3,12 +3,11 @@
 // HBM-bound streaming read of two int64 arrays (16 B per pixel).  Each workgroup keeps
 // several privatised copies of the C*C histogram in LDS (copy chosen by lane, copies offset
 // by one bank) so that the same-bin storms of spatially constant label maps spread over
-// banks; workgroup totals go to a scratch table with plain stores and a second small kernel
-// adds them into the caller's int64 matrix.  Integer arithmetic only: bit-exact and
-// independent of scheduling.
+// banks.  ONE launch per update: a workgroup stores its totals write-through into a scratch
+// table and takes a ticket of its group of workgroups; the last arriver of a group adds the
+// group's rows into the caller's int64 matrix with 64-bit atomics.  Integer arithmetic only:
+// bit-exact and independent of scheduling.
 #include "common.h"
-
-#include <stdlib.h>
 
 #include <hip/hip_fp16.h>
 
@@ -16,7 +15,14 @@ namespace spice {
 
 constexpr int kConfThreads = 512;
 constexpr int kConfMaxBlocks = 1024;
+constexpr int kConfMaxGroups = 128;
 constexpr int kConfLdsBins = 16384;  // 64 KiB of uint32 bins per workgroup at most
+constexpr int64_t kConfMaxPixels = (int64_t)1 << 40;  // a workgroup's uint32 totals cannot wrap below this
+
+// Scratch layout (bytes): [0,8) int64 count of out-of-range predictions, [8,16) reserved,
+// [16, 16 + 4*kConfMaxGroups) one arrival counter per group of workgroups (zero between calls),
+// from kConfHeader on the table of per-workgroup totals, [kConfMaxBlocks][C*C] uint32.
+constexpr size_t kConfHeader = 4096;
 
 struct ConfGeom {
     int copies;
@@ -38,22 +44,51 @@ static inline ConfGeom conf_geom(int C) {
     return g;
 }
 
+SPICE_ENV_KNOB(knob_conf_pixels_per_block, "SPICE_CONF_PIXELS_PER_BLOCK", 0)
+SPICE_ENV_KNOB(knob_conf_group, "SPICE_CONF_GROUP", 0)
+SPICE_ENV_KNOB(knob_argmax_max_blocks, "SPICE_ARGMAX_MAX_BLOCKS", 0)
+
+// Workgroups of the fused arg-max kernel: at most two per compute unit, each lane looping over its
+// pixel groups.  A workgroup waits for its table row to drain and for its ticket before it leaves,
+// so a grid larger than what is resident at once pays that wait twice (measured on MI355X,
+// [8,21,512,512] fp32: 33.7 us with 512 workgroups, 34.8 with 768, 38.5 with 1024).
 static inline int argmax_blocks(int64_t n_threads_needed) {
     int64_t b = ceil_div(n_threads_needed, (int64_t)kConfThreads);
+    const long cap = knob_argmax_max_blocks();
+    int64_t lim = (cap >= 1) ? cap : 2 * (int64_t)device_cu_count();
+    if (lim > kConfMaxBlocks) lim = kConfMaxBlocks;
+    if (b < 1) b = 1;
+    if (b > lim) b = lim;
+    return (int)b;
+}
+
+static inline int conf_blocks(int64_t n_pixels) {
+    // one workgroup per ~4K pixels (two per CU for an 8x512x512 batch), at most kConfMaxBlocks
+    const long v = knob_conf_pixels_per_block();
+    int64_t b = ceil_div(n_pixels, v >= 512 ? (int64_t)v : (int64_t)kConfThreads * 8);
     if (b < 1) b = 1;
     if (b > kConfMaxBlocks) b = kConfMaxBlocks;
     return (int)b;
 }
 
-static inline int conf_blocks(int64_t n_pixels) {
-    // one workgroup per ~8K pixels (one per CU for an 8x512x512 batch), at most kConfMaxBlocks
-    const char *e = getenv("SPICE_CONF_PIXELS_PER_BLOCK");  // tuning knob (host side only)
-    const long v = e ? atol(e) : 0;
-    int64_t b = ceil_div(n_pixels, v >= 512 ? (int64_t)v : (int64_t)kConfThreads * 16);
-    if (b < 1) b = 1;
-    if (b > kConfMaxBlocks) b = kConfMaxBlocks;
-    return (int)b;
+// Workgroups per ticket group: the last arriver of a group reads `group` rows of the table and
+// issues one 64-bit atomic per non-zero bin, so larger groups mean fewer atomics on the caller's
+// matrix and a longer read for the last arriver.
+static inline int conf_group_size(int blocks) {
+    const long v = knob_conf_group();
+    int g = (v >= 1) ? (int)v : 16;
+    const int need = (int)ceil_div(blocks, kConfMaxGroups);
+    if (g < need) g = need;
+    return g;
 }
+
+struct ConfTail {
+    unsigned *partial;              // [gridDim.x][bins]
+    unsigned *tickets;              // [ceil(gridDim.x / group)]
+    unsigned long long *conf;       // [bins], the caller's matrix
+    unsigned long long *bad_total;  // count of out-of-range predictions
+    int group;
+};
 
 struct alignas(16) I64x2 {
     long long x, y;
@@ -69,17 +104,67 @@ __device__ __forceinline__ void conf_count(unsigned *hist, long long t, long lon
     }
 }
 
-// partial: [gridDim.x][C*C] uint32; bad_partial: [gridDim.x] uint32
+// Common end of the histogram kernels.  On entry every LDS atomic of the workgroup has been
+// issued (the caller has not synchronised yet).  The totals of the privatised copies go to this
+// workgroup's row of the table as agent-scope stores (write-through, so no release fence), one
+// lane takes the group's ticket after the stores have drained, and the last arriver adds the
+// group's rows (agent-scope loads: never a stale cached line) into the caller's matrix and
+// returns the ticket to zero for the next call.
+__device__ __forceinline__ void conf_finish(const unsigned *lds_hist, int copies, int stride, int bins,
+                                            unsigned bad, const ConfTail &t) {
+    __shared__ int last_flag;
+    __shared__ unsigned lds_bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) lds_bad = 0;
+    __syncthreads();
+    if (bad) atomicAdd(&lds_bad, bad);
+    unsigned *row = t.partial + (int64_t)blockIdx.x * bins;
+    for (int b = tid; b < bins; b += kConfThreads) {
+        unsigned s = 0;
+        for (int c = 0; c < copies; ++c) s += lds_hist[c * stride + b];
+        __hip_atomic_store(row + b, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int g = blockIdx.x / t.group;
+    const int first = g * t.group;
+    const int members = min(t.group, (int)gridDim.x - first);
+    if (tid == 0) {
+        if (lds_bad) atomicAdd(t.bad_total, (unsigned long long)lds_bad);
+        const unsigned k = __hip_atomic_fetch_add(t.tickets + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (k == (unsigned)(members - 1));
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(t.tickets + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        last_flag = last;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    for (int b = tid; b < bins; b += kConfThreads) {
+        const unsigned *col = t.partial + (int64_t)first * bins + b;
+        unsigned long long s = 0;
+        int m = 0;
+        for (; m + 3 < members; m += 4) {
+            const unsigned v0 = __hip_atomic_load(col + (int64_t)m * bins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned v1 = __hip_atomic_load(col + (int64_t)(m + 1) * bins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned v2 = __hip_atomic_load(col + (int64_t)(m + 2) * bins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned v3 = __hip_atomic_load(col + (int64_t)(m + 3) * bins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s += (unsigned long long)v0 + v1 + v2 + v3;
+        }
+        for (; m < members; ++m)
+            s += __hip_atomic_load(col + (int64_t)m * bins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s) atomicAdd(t.conf + b, s);
+    }
+}
+
 __global__ __launch_bounds__(kConfThreads) void confusion_hist_kernel(
     const long long *__restrict__ preds, const long long *__restrict__ target, int64_t n, int C,
-    int copies, int stride, int vec_ok, unsigned *__restrict__ partial,
-    unsigned *__restrict__ bad_partial) {
+    int copies, int stride, int vec_ok, ConfTail tail) {
     extern __shared__ unsigned lds_hist[];
-    __shared__ unsigned lds_bad;
     const int tid = threadIdx.x;
     const int bins = C * C;
     for (int i = tid; i < copies * stride; i += kConfThreads) lds_hist[i] = 0;
-    if (tid == 0) lds_bad = 0;
     __syncthreads();
 
     unsigned *hist = lds_hist + (tid & (copies - 1)) * stride;
@@ -116,15 +201,7 @@ __global__ __launch_bounds__(kConfThreads) void confusion_hist_kernel(
     }
     for (int64_t i = done + gtid; i < n; i += gthreads) conf_count(hist, target[i], preds[i], C, bad);
 
-    if (bad) atomicAdd(&lds_bad, bad);
-    __syncthreads();
-    unsigned *out = partial + (int64_t)blockIdx.x * bins;
-    for (int b = tid; b < bins; b += kConfThreads) {
-        unsigned s = 0;
-        for (int c = 0; c < copies; ++c) s += lds_hist[c * stride + b];
-        out[b] = s;
-    }
-    if (tid == 0) bad_partial[blockIdx.x] = lds_bad;
+    conf_finish(lds_hist, copies, stride, bins, bad, tail);
 }
 
 // Slow path for class counts whose histogram does not fit LDS: 64-bit global atomics.
@@ -144,49 +221,6 @@ __global__ __launch_bounds__(256) void confusion_global_kernel(const long long *
         }
     }
     if (bad) atomicAdd(bad_total, bad);
-}
-
-// conf[b] += sum over workgroups of partial[g][b].  Grid (ceil(bins/64), kConfReduceY): a
-// workgroup sums its share of the partial rows for 64 bins (8 row slices per bin, combined in
-// LDS) and adds the result with one 64-bit atomic per bin; integer adds commute, so the result
-// does not depend on the order in which workgroups arrive.
-constexpr int kConfReduceY = 8;
-
-__global__ __launch_bounds__(512) void confusion_reduce_kernel(const unsigned *__restrict__ partial,
-                                                               const unsigned *__restrict__ bad_partial,
-                                                               int n_blocks, int bins,
-                                                               long long *__restrict__ conf,
-                                                               long long *__restrict__ bad_total) {
-    __shared__ unsigned long long acc[8][64];
-    const int bl = threadIdx.x & 63;
-    const int slice = threadIdx.x >> 6;
-    const int b = blockIdx.x * 64 + bl;
-    const int step = 8 * gridDim.y;
-    unsigned long long s = 0;
-    if (b < bins) {
-        int g = blockIdx.y * 8 + slice;
-        for (; g + 3 * step < n_blocks; g += 4 * step) {
-            const unsigned v0 = partial[(int64_t)g * bins + b];
-            const unsigned v1 = partial[(int64_t)(g + step) * bins + b];
-            const unsigned v2 = partial[(int64_t)(g + 2 * step) * bins + b];
-            const unsigned v3 = partial[(int64_t)(g + 3 * step) * bins + b];
-            s += (unsigned long long)v0 + v1 + v2 + v3;
-        }
-        for (; g < n_blocks; g += step) s += partial[(int64_t)g * bins + b];
-    }
-    acc[slice][bl] = s;
-    __syncthreads();
-    if (slice == 0 && b < bins) {
-        unsigned long long t = 0;
-        for (int k = 0; k < 8; ++k) t += acc[k][bl];
-        if (t) atomicAdd(reinterpret_cast<unsigned long long *>(conf) + b, t);
-    }
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
-        unsigned long long t = 0;
-        for (int g = threadIdx.x; g < n_blocks; g += 64) t += bad_partial[g];
-        t = (unsigned long long)wave_sum((double)t);  // exact: counts stay far below 2^53
-        if (threadIdx.x == 0 && t) *bad_total += (long long)t;
-    }
 }
 
 // ---- fused argmax + histogram -------------------------------------------------------------
@@ -230,10 +264,90 @@ __device__ __forceinline__ Pack<T, VEC> load_pack(const T *p) {
     }
 }
 
+// Running arg-max of a lane's VEC pixels on the fast path, which is exact for pixels without a NaN:
+// `best` is kept with the NaN-propagating maximum (v_maximum3_f32 / v_pk_maximum3_f16), the index
+// follows `!(v <= best)` (one compare, one select).  A NaN among a pixel's logits ends up in `best`
+// and sends the lane's pixels through the exact one-by-one walk afterwards.
 template <typename T, int VEC>
-__global__ __launch_bounds__(kConfThreads) void argmax_confusion_kernel(
+struct ArgFast {
+    float best[VEC];
+    int arg[VEC];
+    __device__ __forceinline__ void init(const Pack<T, VEC> &x) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            best[e] = to_f32<T>(x.v[e]);
+            arg[e] = 0;
+        }
+    }
+    __device__ __forceinline__ void step(const Pack<T, VEC> &x, int c) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float v = to_f32<T>(x.v[e]);
+            arg[e] = !(v <= best[e]) ? c : arg[e];
+            best[e] = __builtin_elementwise_maximum(best[e], v);
+        }
+    }
+    __device__ __forceinline__ bool any_nan() const {
+        bool r = false;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) r |= best[e] != best[e];
+        return r;
+    }
+};
+
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+// fp16 logits, eight pixels per lane: compared as halves (the order of fp16 values is the order of
+// their fp32 conversions), the running maxima packed two to a register.
+template <>
+struct ArgFast<__half, 8> {
+    f16x2_t best[4];
+    int arg[8];
+    __device__ __forceinline__ void init(const Pack<__half, 8> &x) {
+        const f16x2_t *p = reinterpret_cast<const f16x2_t *>(&x);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) best[k] = p[k];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) arg[e] = 0;
+    }
+    __device__ __forceinline__ void step(const Pack<__half, 8> &x, int c) {
+        const f16x2_t *p = reinterpret_cast<const f16x2_t *>(&x);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f16x2_t v = p[k];
+            arg[2 * k] = !(v.x <= best[k].x) ? c : arg[2 * k];
+            arg[2 * k + 1] = !(v.y <= best[k].y) ? c : arg[2 * k + 1];
+            best[k] = __builtin_elementwise_maximum(best[k], v);
+        }
+    }
+    __device__ __forceinline__ bool any_nan() const {
+        bool r = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r |= (best[k].x != best[k].x) | (best[k].y != best[k].y);
+        return r;
+    }
+};
+
+template <typename T, int VEC>
+__device__ __forceinline__ void load_planes4(Pack<T, VEC> (&x)[4], const T *base, int c, int64_t HW) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = load_pack<T, VEC>(base + (int64_t)(c + k) * HW);
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ void use_planes4(ArgFast<T, VEC> &f, const Pack<T, VEC> (&x)[4], int c) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) f.step(x[k], c + k);
+}
+
+// The class axis is walked four planes at a time with the next four already requested (two
+// register sets, A and B), so every wave overlaps its compares with its own loads instead of
+// relying on other waves being in another phase: all workgroups start together and would
+// otherwise alternate between loading and comparing in step.
+template <typename T, int VEC, bool WIDE>
+__global__ __launch_bounds__(kConfThreads, 4) void argmax_confusion_kernel(
     const T *__restrict__ logits, const long long *__restrict__ target, int64_t N, int64_t HW, int C,
-    int copies, int stride, unsigned *__restrict__ partial, unsigned *__restrict__ bad_partial) {
+    int copies, int stride, ConfTail tail) {
     extern __shared__ unsigned lds_hist[];
     const int tid = threadIdx.x;
     const int bins = C * C;
@@ -248,7 +362,7 @@ __global__ __launch_bounds__(kConfThreads) void argmax_confusion_kernel(
         const int64_t r = (q - n * per_img) * VEC;
         const T *base = logits + n * C * HW + r;
         // labels first, reduced to a row offset at once (-1 = skip): consumed here, so their loads
-        // are issued with the first class plane instead of one by one behind the class loop
+        // are issued with the first class planes instead of one by one behind the class loop
         const long long *tp = target + n * HW + r;
         int trow[VEC];
 #pragma unroll
@@ -256,62 +370,93 @@ __global__ __launch_bounds__(kConfThreads) void argmax_confusion_kernel(
             const long long t = tp[e];
             trow[e] = (t >= 0 && t < C) ? (int)t * C : -1;
         }
-        float best[VEC];
         int arg[VEC];
-        {
-            const Pack<T, VEC> x = load_pack<T, VEC>(base);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                best[e] = to_f32<T>(x.v[e]);
-                arg[e] = 0;
+        bool slow = !WIDE;
+        if (WIDE) {
+            ArgFast<T, VEC> f;
+            Pack<T, VEC> a[4], b[4];
+            const Pack<T, VEC> x0 = load_pack<T, VEC>(base);
+            int c = 1;
+            if (c + 3 < C) load_planes4<T, VEC>(a, base, c, HW);
+            f.init(x0);
+            if (c + 3 < C) {
+                for (; c + 11 < C; c += 8) {
+                    load_planes4<T, VEC>(b, base, c + 4, HW);
+                    use_planes4<T, VEC>(f, a, c);
+                    load_planes4<T, VEC>(a, base, c + 8, HW);
+                    use_planes4<T, VEC>(f, b, c + 4);
+                }
+                if (c + 7 < C) {
+                    load_planes4<T, VEC>(b, base, c + 4, HW);
+                    use_planes4<T, VEC>(f, a, c);
+                    use_planes4<T, VEC>(f, b, c + 4);
+                    c += 8;
+                } else {
+                    use_planes4<T, VEC>(f, a, c);
+                    c += 4;
+                }
             }
-        }
-        int c = 1;
-        for (; c + 3 < C; c += 4) {
-            const Pack<T, VEC> x0 = load_pack<T, VEC>(base + (int64_t)c * HW);
-            const Pack<T, VEC> x1 = load_pack<T, VEC>(base + (int64_t)(c + 1) * HW);
-            const Pack<T, VEC> x2 = load_pack<T, VEC>(base + (int64_t)(c + 2) * HW);
-            const Pack<T, VEC> x3 = load_pack<T, VEC>(base + (int64_t)(c + 3) * HW);
+            for (; c < C; ++c) f.step(load_pack<T, VEC>(base + (int64_t)c * HW), c);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                argmax_step(to_f32<T>(x0.v[e]), c, best[e], arg[e]);
-                argmax_step(to_f32<T>(x1.v[e]), c + 1, best[e], arg[e]);
-                argmax_step(to_f32<T>(x2.v[e]), c + 2, best[e], arg[e]);
-                argmax_step(to_f32<T>(x3.v[e]), c + 3, best[e], arg[e]);
+            for (int e = 0; e < VEC; ++e) arg[e] = f.arg[e];
+            slow = f.any_nan();
+        }
+        if (slow) {  // exact walk, class by class: a NaN is the maximum, the first maximum wins
+            float best[VEC];
+            {
+                const Pack<T, VEC> x = load_pack<T, VEC>(base);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    best[e] = to_f32<T>(x.v[e]);
+                    arg[e] = 0;
+                }
             }
-        }
-        for (; c < C; ++c) {
-            const Pack<T, VEC> x0 = load_pack<T, VEC>(base + (int64_t)c * HW);
+            for (int c = 1; c < C; ++c) {
+                const Pack<T, VEC> x = load_pack<T, VEC>(base + (int64_t)c * HW);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) argmax_step(to_f32<T>(x0.v[e]), c, best[e], arg[e]);
+                for (int e = 0; e < VEC; ++e) argmax_step(to_f32<T>(x.v[e]), c, best[e], arg[e]);
+            }
         }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             if (trow[e] >= 0) atomicAdd(&hist[trow[e] + arg[e]], 1u);
         }
     }
-    __syncthreads();
-    unsigned *out = partial + (int64_t)blockIdx.x * bins;
-    for (int b = tid; b < bins; b += kConfThreads) {
-        unsigned s = 0;
-        for (int k = 0; k < copies; ++k) s += lds_hist[k * stride + b];
-        out[b] = s;
-    }
-    if (tid == 0) bad_partial[blockIdx.x] = 0;
+    conf_finish(lds_hist, copies, stride, bins, 0u, tail);
 }
 
-// Workspace layout (bytes): [0,8) int64 count of out-of-range predictions (caller zeroes once),
-// [8,16) reserved, [16, 16+4*kConfMaxBlocks) per-workgroup bad counts, then the partial table.
-constexpr size_t kConfHeader = 16 + 4 * (size_t)kConfMaxBlocks;
-
-template <typename T, int VEC>
+template <typename T, int VEC, bool WIDE>
 static int launch_argmax(const void *logits, const int64_t *target, int64_t n, int64_t hw, int C,
-                         const ConfGeom &g, int blocks, unsigned *partial, unsigned *bad_partial,
-                         hipStream_t st) {
-    hipLaunchKernelGGL((argmax_confusion_kernel<T, VEC>), dim3(blocks), dim3(kConfThreads),
+                         const ConfGeom &g, int blocks, const ConfTail &tail, hipStream_t st) {
+    hipLaunchKernelGGL((argmax_confusion_kernel<T, VEC, WIDE>), dim3(blocks), dim3(kConfThreads),
                        (size_t)g.copies * g.stride * 4, st, static_cast<const T *>(logits),
-                       reinterpret_cast<const long long *>(target), n, hw, C, g.copies, g.stride,
-                       partial, bad_partial);
+                       reinterpret_cast<const long long *>(target), n, hw, C, g.copies, g.stride, tail);
+    SPICE_LAUNCH_CHECK();
+    return SPICE_OK;
+}
+
+static ConfTail conf_tail(void *scratch, int64_t *conf, int64_t *invalid_count, int blocks) {
+    char *ws = static_cast<char *>(scratch);
+    ConfTail t;
+    t.partial = reinterpret_cast<unsigned *>(ws + kConfHeader);
+    t.tickets = reinterpret_cast<unsigned *>(ws + 16);
+    t.conf = reinterpret_cast<unsigned long long *>(conf);
+    t.bad_total = reinterpret_cast<unsigned long long *>(invalid_count ? (void *)invalid_count : (void *)ws);
+    t.group = conf_group_size(blocks);
+    return t;
+}
+
+// The update itself, on a scratch area laid out as above (caller workspace or the static array).
+static int confusion_update_on(const int64_t *preds, const int64_t *target, int64_t n_pixels, int num_classes,
+                               int64_t *conf, void *scratch, int64_t *invalid_count, hipStream_t st) {
+    const ConfGeom g = conf_geom(num_classes);
+    const int blocks = conf_blocks(n_pixels);
+    const int vec_ok = aligned16(preds) && aligned16(target);
+    hipLaunchKernelGGL(confusion_hist_kernel, dim3(blocks), dim3(kConfThreads),
+                       (size_t)g.copies * g.stride * 4, st,
+                       reinterpret_cast<const long long *>(preds),
+                       reinterpret_cast<const long long *>(target), n_pixels, num_classes,
+                       g.copies, g.stride, vec_ok, conf_tail(scratch, conf, invalid_count, blocks));
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;
 }
@@ -332,7 +477,7 @@ extern "C" int spice_confusion_update(const int64_t *preds, const int64_t *targe
                                       int32_t num_classes, int64_t *conf, void *workspace,
                                       size_t workspace_bytes, void *stream) {
     if (n_pixels < 0 || num_classes < 1) return SPICE_ERR_ARG;
-    if (num_classes > 46340) return SPICE_ERR_UNSUPPORTED;
+    if (num_classes > 46340 || n_pixels > kConfMaxPixels) return SPICE_ERR_UNSUPPORTED;
     if (n_pixels == 0) return SPICE_OK;
     if (!preds || !target || !conf || !workspace) return SPICE_ERR_ARG;
     if (!aligned8(preds) || !aligned8(target) || !aligned8(conf) || !aligned16(workspace))
@@ -340,8 +485,6 @@ extern "C" int spice_confusion_update(const int64_t *preds, const int64_t *targe
     if (workspace_bytes < spice_confusion_workspace_bytes(n_pixels, num_classes))
         return SPICE_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    char *ws = static_cast<char *>(workspace);
-    long long *bad_total = reinterpret_cast<long long *>(ws);
     const int64_t bins = (int64_t)num_classes * num_classes;
     if (bins > kConfLdsBins) {
         int64_t blocks = ceil_div(n_pixels, 256 * 8);
@@ -350,26 +493,11 @@ extern "C" int spice_confusion_update(const int64_t *preds, const int64_t *targe
                            reinterpret_cast<const long long *>(preds),
                            reinterpret_cast<const long long *>(target), n_pixels,
                            (int64_t)num_classes, reinterpret_cast<unsigned long long *>(conf),
-                           reinterpret_cast<unsigned long long *>(bad_total));
+                           reinterpret_cast<unsigned long long *>(workspace));
         SPICE_LAUNCH_CHECK();
         return SPICE_OK;
     }
-    unsigned *bad_partial = reinterpret_cast<unsigned *>(ws + 16);
-    unsigned *partial = reinterpret_cast<unsigned *>(ws + kConfHeader);
-    const ConfGeom g = conf_geom(num_classes);
-    const int blocks = conf_blocks(n_pixels);
-    const int vec_ok = aligned16(preds) && aligned16(target);
-    hipLaunchKernelGGL(confusion_hist_kernel, dim3(blocks), dim3(kConfThreads),
-                       (size_t)g.copies * g.stride * 4, st,
-                       reinterpret_cast<const long long *>(preds),
-                       reinterpret_cast<const long long *>(target), n_pixels, (int)num_classes,
-                       g.copies, g.stride, vec_ok, partial, bad_partial);
-    SPICE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(confusion_reduce_kernel, dim3((unsigned)ceil_div(bins, 64), kConfReduceY), dim3(512), 0, st,
-                       partial, bad_partial, blocks, (int)bins, reinterpret_cast<long long *>(conf),
-                       bad_total);
-    SPICE_LAUNCH_CHECK();
-    return SPICE_OK;
+    return confusion_update_on(preds, target, n_pixels, num_classes, conf, workspace, nullptr, st);
 }
 
 extern "C" int spice_argmax_confusion_update(const void *logits, int32_t logits_dtype,
@@ -381,42 +509,27 @@ extern "C" int spice_argmax_confusion_update(const void *logits, int32_t logits_
     const int64_t bins = (int64_t)num_classes * num_classes;
     if (bins > kConfLdsBins) return SPICE_ERR_UNSUPPORTED;
     if (n == 0 || hw == 0) return SPICE_OK;
+    if (n > kConfMaxPixels / hw) return SPICE_ERR_UNSUPPORTED;
     if (!logits || !target || !conf || !workspace) return SPICE_ERR_ARG;
     if (!aligned8(target) || !aligned8(conf) || !aligned16(workspace)) return SPICE_ERR_ARG;
     if (workspace_bytes < spice_confusion_workspace_bytes(n * hw, num_classes))
         return SPICE_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    char *ws = static_cast<char *>(workspace);
-    unsigned *bad_partial = reinterpret_cast<unsigned *>(ws + 16);
-    unsigned *partial = reinterpret_cast<unsigned *>(ws + kConfHeader);
     const ConfGeom g = conf_geom(num_classes);
     const int C = num_classes;
-    int rc;
     if (logits_dtype == 0) {
         const bool v4 = aligned16(logits) && (hw % 4 == 0);
         const int blocks = argmax_blocks(n * hw / (v4 ? 4 : 1));
-        rc = v4 ? launch_argmax<float, 4>(logits, target, n, hw, C, g, blocks, partial, bad_partial, st)
-                : launch_argmax<float, 1>(logits, target, n, hw, C, g, blocks, partial, bad_partial, st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(confusion_reduce_kernel, dim3((unsigned)ceil_div(bins, 64), kConfReduceY), dim3(512), 0,
-                           st, partial, bad_partial, blocks, (int)bins,
-                           reinterpret_cast<long long *>(conf), reinterpret_cast<long long *>(ws));
-    } else {
-        const bool v8 = aligned16(logits) && (hw % 8 == 0);
-        const int blocks = argmax_blocks(n * hw / (v8 ? 8 : 1));
-        if (logits_dtype == 1)
-            rc = v8 ? launch_argmax<__half, 8>(logits, target, n, hw, C, g, blocks, partial, bad_partial, st)
-                    : launch_argmax<__half, 1>(logits, target, n, hw, C, g, blocks, partial, bad_partial, st);
-        else
-            rc = v8 ? launch_argmax<unsigned short, 8>(logits, target, n, hw, C, g, blocks, partial,
-                                                       bad_partial, st)
-                    : launch_argmax<unsigned short, 1>(logits, target, n, hw, C, g, blocks, partial,
-                                                       bad_partial, st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(confusion_reduce_kernel, dim3((unsigned)ceil_div(bins, 64), kConfReduceY), dim3(512), 0,
-                           st, partial, bad_partial, blocks, (int)bins,
-                           reinterpret_cast<long long *>(conf), reinterpret_cast<long long *>(ws));
+        const ConfTail tail = conf_tail(workspace, conf, nullptr, blocks);
+        return v4 ? launch_argmax<float, 4, true>(logits, target, n, hw, C, g, blocks, tail, st)
+                  : launch_argmax<float, 1, false>(logits, target, n, hw, C, g, blocks, tail, st);
     }
-    SPICE_LAUNCH_CHECK();
-    return SPICE_OK;
+    const bool v8 = aligned16(logits) && (hw % 8 == 0);
+    const int blocks = argmax_blocks(n * hw / (v8 ? 8 : 1));
+    const ConfTail tail = conf_tail(workspace, conf, nullptr, blocks);
+    if (logits_dtype == 1)
+        return v8 ? launch_argmax<__half, 8, true>(logits, target, n, hw, C, g, blocks, tail, st)
+                  : launch_argmax<__half, 1, false>(logits, target, n, hw, C, g, blocks, tail, st);
+    return v8 ? launch_argmax<unsigned short, 8, true>(logits, target, n, hw, C, g, blocks, tail, st)
+              : launch_argmax<unsigned short, 1, false>(logits, target, n, hw, C, g, blocks, tail, st);
 }

@@ -699,42 +699,28 @@ __global__ __launch_bounds__(256) void scale_inplace_kernel(float *x, int64_t n,
 
 constexpr size_t kLdsPerCu = 160 * 1024;
 
-static int device_cu_count() {
-    static int cached[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (cached[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-        cached[dev] = n;
-    }
-    return cached[dev];
-}
-
 // Workgroups of the loss kernel, each looping over its tiles.  Measured on MI355X (256 CUs): the
 // plain loss inside the sweep step 65.8 us with two per CU and 66.8 us with three (standalone on
 // cold inputs 65.8 / 64.1 us); with the boundary / confidence options, whose register use allows
 // exactly three resident workgroups per CU, 76.9 us with two and 70.1 us with three.  With few classes
 // a tile is short (48 bytes per pixel at 5 classes against 176 at 21) and more workgroups are needed
 // to keep as many bytes in flight: [32,5,576,576] takes 118 us with two per CU, 102 us with four.
+SPICE_ENV_KNOB(knob_kd_max_blocks, "SPICE_KD_MAX_BLOCKS", 0)       // tuning knobs (host side only)
+SPICE_ENV_KNOB(knob_kd_stage, "SPICE_KD_STAGE", 1)                 // 0 = never stage the gradient pass in LDS
+SPICE_ENV_KNOB(knob_kd_regs, "SPICE_KD_REGS", 1)                   // 0 = never keep the logits in registers for the gradient
+SPICE_ENV_KNOB(knob_kd_stage_blocks, "SPICE_KD_STAGE_BLOCKS", 0)
+
 static int kd_max_blocks(bool ext, int64_t classes) {
-    const char *e = getenv("SPICE_KD_MAX_BLOCKS");  // tuning knob (host side only)
-    const int v = e ? atoi(e) : 0;
+    const int v = (int)knob_kd_max_blocks();
     if (v >= 1 && v <= kKdMaxBlocks) return v;
     const int per_cu = classes <= 8 ? 4 : (ext ? 3 : 2);
     const int d = per_cu * device_cu_count();
     return d < kKdMaxBlocks ? d : kKdMaxBlocks;
 }
 
-static int kd_stage_mode() {
-    const char *e = getenv("SPICE_KD_STAGE");  // tuning knob: 0 = never stage the gradient pass in LDS
-    return e ? atoi(e) : 1;
-}
+static int kd_stage_mode() { return (int)knob_kd_stage(); }
 
-static int kd_regs_mode() {
-    const char *e = getenv("SPICE_KD_REGS");  // tuning knob: 0 = never keep the logits in registers for the gradient
-    return e ? atoi(e) : 1;
-}
+static int kd_regs_mode() { return (int)knob_kd_regs(); }
 
 template <int VEC>
 static int kd_launch(const KdArgs &a, bool grad, bool ext, int blocks, hipStream_t st) {
@@ -877,8 +863,7 @@ extern "C" int spice_kdlite_forward(const float *student, const float *teacher, 
             if (per_cu > 8) per_cu = 8;
             if (per_cu < 1) per_cu = 1;
             int64_t lim = per_cu * device_cu_count();
-            const char *e = getenv("SPICE_KD_STAGE_BLOCKS");  // tuning knob
-            const int cap = e ? atoi(e) : 0;
+            const int cap = (int)knob_kd_stage_blocks();
             if (cap >= 1) lim = cap;
             if (lim > kKdMaxBlocks) lim = kKdMaxBlocks;
             if (b1 > lim) b1 = lim;

@@ -1,0 +1,360 @@
+// torch.ops.spice.*: the thin PyTorch extension over the C ABI of libspice_amd.so.
+//
+// Every operator takes at::Tensor arguments, checks device / dtype / contiguity / shape with
+// TORCH_CHECK, makes the tensors' device current, takes torch's current HIP stream of that device
+// and calls the extern "C" launcher declared in include/spice_amd.h.  Nothing is computed here and
+// nothing falls back to stock ATen kernels, with one stated exception (conv1x1_f16, see there).
+// Host-only planning (spice_*_plan) is not wrapped: it touches no tensor and stays a plain C call.
+//
+// Python surfaces these operators stand under (reference file:line):
+//   compute_taylor_scores          pruning/sensitivity_utils.py:15-73     -> importance_run
+//   tp MagnitudeImportance         pruning/pruner.py:268-270              -> importance_run, importance_cols_run
+//   pruner.step() slicing          pruning/pruner.py:495                  -> gather_run
+//   KDLiteLoss.forward             pruning/losses.py:127-162              -> kdlite_forward, scale_inplace
+//   update_confusion_matrix        baseline/eval/metrics.py:8-19          -> confusion_update
+//   argmax + update                baseline/eval/inference.py:47-48       -> argmax_confusion_update
+#include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include <algorithm>
+#include <limits>
+#include <tuple>
+#include <vector>
+
+#include "../../include/spice_amd.h"
+
+namespace {
+
+using at::Tensor;
+
+void *current_stream(const Tensor &t) {
+    return static_cast<void *>(c10::hip::getCurrentHIPStream(t.device().index()).stream());
+}
+
+void check_rc(int rc, const char *what) {
+    if (rc == SPICE_OK) return;
+    TORCH_CHECK_VALUE(rc != SPICE_ERR_ARG, what, ": ", spice_error_string(rc));
+    TORCH_CHECK(false, what, ": ", spice_error_string(rc), " (code ", rc, ")");
+}
+
+void check_dev(const Tensor &t, const char *name, at::ScalarType dtype) {
+    TORCH_CHECK(t.is_cuda(), name, " is on ", t.device(),
+                "; the MI355X path has no CPU implementation (move the tensor to a HIP device)");
+    TORCH_CHECK_TYPE(t.scalar_type() == dtype, name, " must be ", dtype, ", got ", t.scalar_type());
+    TORCH_CHECK_VALUE(t.is_contiguous(), name, " must be contiguous");
+}
+
+void check_same_device(const Tensor &a, const Tensor &b, const char *name) {
+    TORCH_CHECK(a.device() == b.device(), name, " is on ", b.device(), ", expected ", a.device());
+}
+
+// Lowest data pointer of a list of tensors: work-item tables address every tensor of a model as an
+// element offset from it.
+const float *list_base(const std::vector<Tensor> &ts, const char *name, const Tensor &like) {
+    TORCH_CHECK_VALUE(!ts.empty(), name, ": no tensors");
+    uintptr_t base = std::numeric_limits<uintptr_t>::max();
+    for (const Tensor &t : ts) {
+        check_dev(t, name, at::kFloat);
+        check_same_device(like, t, name);
+        base = std::min(base, reinterpret_cast<uintptr_t>(t.data_ptr()));
+    }
+    return reinterpret_cast<const float *>(base);
+}
+
+void check_items(const Tensor &items, int64_t n_items, size_t item_bytes, const char *name, const Tensor &like) {
+    check_dev(items, name, at::kByte);
+    check_same_device(like, items, name);
+    TORCH_CHECK_VALUE(n_items >= 0 && items.numel() >= (int64_t)(n_items * item_bytes), name, " holds ",
+                      items.numel(), " bytes, fewer than ", n_items, " records of ", item_bytes, " bytes");
+}
+
+// ---- (1) importance -------------------------------------------------------------------------
+
+void importance_run(std::vector<Tensor> weights, std::vector<Tensor> grads, Tensor scores, const Tensor &items,
+                    int64_t n_items, int64_t mode, bool accumulate) {
+    check_dev(scores, "scores", at::kFloat);
+    const float *w_base = list_base(weights, "weights", scores);
+    const float *g_base = nullptr;
+    if (mode == SPICE_IMP_TAYLOR) {
+        TORCH_CHECK_VALUE(grads.size() == weights.size(), "importance_run: Taylor mode needs one gradient per weight");
+        g_base = list_base(grads, "grads", scores);
+    }
+    check_items(items, n_items, sizeof(spice_rows_item), "items", scores);
+    c10::DeviceGuard guard(scores.device());
+    check_rc(spice_importance_run(w_base, g_base, scores.data_ptr<float>(),
+                                  reinterpret_cast<const spice_rows_item *>(items.data_ptr()), n_items, (int32_t)mode,
+                                  accumulate ? 1 : 0, current_stream(scores)),
+             "spice_importance_run");
+}
+
+void importance_cols_run(std::vector<Tensor> weights, Tensor scores, Tensor partial, const Tensor &items,
+                         int64_t n_items, const Tensor &folds, int64_t n_folds, int64_t mode) {
+    check_dev(scores, "scores", at::kFloat);
+    check_dev(partial, "partial", at::kFloat);
+    check_same_device(scores, partial, "partial");
+    const float *w_base = list_base(weights, "weights", scores);
+    check_items(items, n_items, sizeof(spice_cols_item), "items", scores);
+    check_items(folds, n_folds, sizeof(spice_cols_fold), "folds", scores);
+    c10::DeviceGuard guard(scores.device());
+    check_rc(spice_importance_cols_run(w_base, scores.data_ptr<float>(), partial.data_ptr<float>(),
+                                       reinterpret_cast<const spice_cols_item *>(items.data_ptr()), n_items,
+                                       reinterpret_cast<const spice_cols_fold *>(folds.data_ptr()), n_folds,
+                                       (int32_t)mode, current_stream(scores)),
+             "spice_importance_cols_run");
+}
+
+// ---- (4) gather -----------------------------------------------------------------------------
+
+void gather_run(std::vector<Tensor> srcs, Tensor dst, const Tensor &idx, const Tensor &items, int64_t n_items) {
+    check_dev(dst, "dst", at::kFloat);
+    check_dev(idx, "idx", at::kLong);
+    check_same_device(dst, idx, "idx");
+    const float *src_base = list_base(srcs, "srcs", dst);
+    check_items(items, n_items, sizeof(spice_gather_item), "items", dst);
+    c10::DeviceGuard guard(dst.device());
+    check_rc(spice_gather_run(src_base, dst.data_ptr<float>(), idx.data_ptr<int64_t>(),
+                              reinterpret_cast<const spice_gather_item *>(items.data_ptr()), n_items,
+                              current_stream(dst)),
+             "spice_gather_run");
+}
+
+// ---- (3) confusion --------------------------------------------------------------------------
+
+void check_conf(const Tensor &conf, int64_t num_classes) {
+    check_dev(conf, "conf", at::kLong);
+    TORCH_CHECK_VALUE(num_classes >= 1 && num_classes <= std::numeric_limits<int32_t>::max(), "num_classes must be >= 1");
+    TORCH_CHECK_VALUE(conf.dim() == 2 && conf.size(0) == num_classes && conf.size(1) == num_classes, "conf must be [",
+                      num_classes, ",", num_classes, "], got ", conf.sizes());
+}
+
+void confusion_update(Tensor conf, const Tensor &preds, const Tensor &target, int64_t num_classes, Tensor workspace) {
+    check_conf(conf, num_classes);
+    check_dev(preds, "preds", at::kLong);
+    check_dev(target, "target", at::kLong);
+    check_dev(workspace, "workspace", at::kByte);
+    check_same_device(conf, preds, "preds");
+    check_same_device(conf, target, "target");
+    check_same_device(conf, workspace, "workspace");
+    TORCH_CHECK_VALUE(preds.numel() == target.numel(), "preds and target differ in element count");
+    c10::DeviceGuard guard(conf.device());
+    check_rc(spice_confusion_update(preds.data_ptr<int64_t>(), target.data_ptr<int64_t>(), preds.numel(),
+                                    (int32_t)num_classes, conf.data_ptr<int64_t>(), workspace.data_ptr(),
+                                    (size_t)workspace.numel(), current_stream(conf)),
+             "spice_confusion_update");
+}
+
+int32_t logits_code(const Tensor &t, const char *name) {
+    switch (t.scalar_type()) {
+        case at::kFloat: return 0;
+        case at::kHalf: return 1;
+        case at::kBFloat16: return 2;
+        default: TORCH_CHECK_TYPE(false, name, " dtype ", t.scalar_type(), " not supported");
+    }
+    return -1;
+}
+
+void argmax_confusion_update(Tensor conf, const Tensor &logits, const Tensor &target, int64_t num_classes,
+                             Tensor workspace) {
+    check_conf(conf, num_classes);
+    const int32_t code = logits_code(logits, "logits");
+    check_dev(logits, "logits", logits.scalar_type());
+    check_dev(target, "target", at::kLong);
+    check_dev(workspace, "workspace", at::kByte);
+    check_same_device(conf, logits, "logits");
+    check_same_device(conf, target, "target");
+    check_same_device(conf, workspace, "workspace");
+    TORCH_CHECK_VALUE(logits.dim() >= 2 && logits.size(1) == num_classes, "logits must be [N, num_classes, ...]");
+    const int64_t n = logits.size(0);
+    const int64_t hw = (n * num_classes) ? logits.numel() / (n * num_classes) : 0;
+    TORCH_CHECK_VALUE(target.numel() == n * hw, "target must have N*H*W elements");
+    c10::DeviceGuard guard(conf.device());
+    check_rc(spice_argmax_confusion_update(logits.data_ptr(), code, target.data_ptr<int64_t>(), n, hw,
+                                           (int32_t)num_classes, conf.data_ptr<int64_t>(), workspace.data_ptr(),
+                                           (size_t)workspace.numel(), current_stream(conf)),
+             "spice_argmax_confusion_update");
+}
+
+// ---- (2) KD-Lite ----------------------------------------------------------------------------
+
+std::tuple<Tensor, Tensor> kdlite_forward(const Tensor &student, const Tensor &teacher, const Tensor &labels,
+                                          double temperature, double alpha, int64_t ignore_index,
+                                          double boundary_weight, bool confidence_weight,
+                                          const c10::optional<Tensor> &class_weight, bool want_grad, double coef_ce,
+                                          double coef_kd, const c10::optional<Tensor> &upstream, Tensor workspace) {
+    check_dev(student, "student_logits", at::kFloat);
+    check_dev(teacher, "teacher_logits", at::kFloat);
+    check_dev(labels, "labels", at::kLong);
+    check_dev(workspace, "workspace", at::kByte);
+    check_same_device(student, teacher, "teacher_logits");
+    check_same_device(student, labels, "labels");
+    check_same_device(student, workspace, "workspace");
+    TORCH_CHECK_VALUE(student.dim() == 4 && teacher.sizes() == student.sizes(),
+                      "student/teacher logits must both be [N,C,H,W]");
+    const int64_t n = student.size(0), c = student.size(1), h = student.size(2), w = student.size(3);
+    TORCH_CHECK_VALUE(labels.dim() == 3 && labels.size(0) == n && labels.size(1) == h && labels.size(2) == w,
+                      "labels must be [", n, ",", h, ",", w, "], got ", labels.sizes());
+    spice_kdlite_params p;
+    p.temperature = (float)temperature;
+    p.alpha = (float)alpha;
+    p.boundary_weight = (float)boundary_weight;
+    p.confidence_weight = confidence_weight ? 1 : 0;
+    p.ignore_index = ignore_index;
+    p.class_weight = nullptr;
+    if (class_weight.has_value()) {
+        check_dev(*class_weight, "class_weight", at::kFloat);
+        check_same_device(student, *class_weight, "class_weight");
+        TORCH_CHECK_VALUE(class_weight->numel() == c, "class_weight must have C elements");
+        p.class_weight = class_weight->data_ptr<float>();
+    }
+    const float *up = nullptr;
+    if (upstream.has_value()) {
+        check_dev(*upstream, "upstream", at::kFloat);
+        check_same_device(student, *upstream, "upstream");
+        TORCH_CHECK_VALUE(upstream->numel() == 3, "upstream must have 3 elements");
+        up = upstream->data_ptr<float>();
+    }
+    c10::DeviceGuard guard(student.device());
+    Tensor out3 = at::empty({3}, student.options());
+    Tensor grad = want_grad ? at::empty_like(student) : at::empty({0}, student.options());
+    check_rc(spice_kdlite_forward(student.data_ptr<float>(), teacher.data_ptr<float>(), labels.data_ptr<int64_t>(), n, c,
+                                  h, w, &p, out3.data_ptr<float>(), want_grad ? grad.data_ptr<float>() : nullptr,
+                                  (float)coef_ce, (float)coef_kd, up, workspace.data_ptr(), (size_t)workspace.numel(),
+                                  current_stream(student)),
+             "spice_kdlite_forward");
+    return std::make_tuple(out3, grad);
+}
+
+void scale_inplace(Tensor x, const Tensor &scale) {
+    check_dev(x, "x", at::kFloat);
+    check_dev(scale, "scale", at::kFloat);
+    check_same_device(x, scale, "scale");
+    TORCH_CHECK_VALUE(scale.numel() >= 1, "scale must hold one float");
+    c10::DeviceGuard guard(x.device());
+    check_rc(spice_scale_inplace(x.data_ptr<float>(), x.numel(), scale.data_ptr<float>(), current_stream(x)),
+             "spice_scale_inplace");
+}
+
+// ---- kernels inside the candidate's forward ----------------------------------------------------
+
+int32_t act_code(const Tensor &t, const char *name) {
+    if (t.scalar_type() == at::kFloat) return 0;
+    TORCH_CHECK_TYPE(t.scalar_type() == at::kHalf, name, ": dtype ", t.scalar_type(), " not supported");
+    return 1;
+}
+
+Tensor upsample_bilinear(const Tensor &x, int64_t out_h, int64_t out_w, bool align_corners, double scale_h,
+                         double scale_w, int64_t out_dtype) {
+    const int32_t in_code = act_code(x, "upsample_bilinear");
+    check_dev(x, "x", x.scalar_type());
+    TORCH_CHECK_VALUE(x.dim() == 4, "upsample_bilinear: x must be [N, C, H, W]");
+    TORCH_CHECK_TYPE(out_dtype == 0 || out_dtype == 1, "upsample_bilinear: output dtype code ", out_dtype,
+                     " not supported");
+    c10::DeviceGuard guard(x.device());
+    Tensor out = at::empty({x.size(0), x.size(1), out_h, out_w}, x.options().dtype(out_dtype == 0 ? at::kFloat : at::kHalf));
+    check_rc(spice_upsample_bilinear(x.data_ptr(), in_code, out.data_ptr(), (int32_t)out_dtype, x.size(0) * x.size(1),
+                                     (int32_t)x.size(2), (int32_t)x.size(3), (int32_t)out_h, (int32_t)out_w,
+                                     align_corners ? 1 : 0, (float)scale_h, (float)scale_w, current_stream(x)),
+             "spice_upsample_bilinear");
+    return out;
+}
+
+Tensor bn_act(const Tensor &x, const Tensor &mean, const Tensor &var, const Tensor &weight, const Tensor &bias,
+              double eps, const c10::optional<Tensor> &residual, bool relu) {
+    const int32_t code = act_code(x, "bn_act");
+    TORCH_CHECK(x.is_cuda(), "x is on ", x.device(),
+                "; the MI355X path has no CPU implementation (move the tensor to a HIP device)");
+    TORCH_CHECK_VALUE(x.dim() == 4 && x.is_contiguous(), "bn_act: x must be a contiguous [N, C, H, W] tensor");
+    const int64_t c = x.size(1);
+    for (const Tensor *t : {&mean, &var, &weight, &bias})
+        TORCH_CHECK_TYPE(t->scalar_type() == at::kFloat && t->device() == x.device() && t->numel() == c &&
+                             t->is_contiguous(),
+                         "bn_act: the four parameter vectors must be contiguous fp32 [", c, "] on ", x.device());
+    const void *res = nullptr;
+    if (residual.has_value()) {
+        TORCH_CHECK_VALUE(residual->sizes() == x.sizes(), "bn_act: residual must have x's shape");
+        TORCH_CHECK_TYPE(residual->scalar_type() == x.scalar_type() && residual->device() == x.device() &&
+                             residual->is_contiguous(),
+                         "bn_act: residual must be contiguous, of x's dtype and on x's device");
+        res = residual->data_ptr();
+    }
+    c10::DeviceGuard guard(x.device());
+    Tensor out = at::empty_like(x);
+    check_rc(spice_bn_act(x.data_ptr(), res, out.data_ptr(), code, mean.data_ptr<float>(), var.data_ptr<float>(),
+                          weight.data_ptr<float>(), bias.data_ptr<float>(), (float)eps, x.size(0), c,
+                          x.size(2) * x.size(3), relu ? 1 : 0, current_stream(x)),
+             "spice_bn_act");
+    return out;
+}
+
+Tensor depthwise_conv3x3(const Tensor &x, const Tensor &weight, int64_t dilation) {
+    check_dev(x, "x", at::kHalf);
+    TORCH_CHECK_TYPE(weight.scalar_type() == at::kHalf || weight.scalar_type() == at::kFloat,
+                     "depthwise_conv3x3: weight dtype ", weight.scalar_type(), " not supported");
+    check_dev(weight, "weight", weight.scalar_type());
+    check_same_device(x, weight, "weight");
+    TORCH_CHECK_VALUE(x.dim() == 4 && weight.dim() == 4 && weight.size(0) == x.size(1) && weight.size(1) == 1 &&
+                          weight.size(2) == 3 && weight.size(3) == 3,
+                      "depthwise_conv3x3: x must be [N,C,H,W] and weight [C,1,3,3]");
+    c10::DeviceGuard guard(x.device());
+    Tensor out = at::empty_like(x);
+    const int32_t wcode = weight.scalar_type() == at::kFloat ? 0 : 1;
+    const int rc = dilation == 1
+                       ? spice_depthwise_conv3x3(x.data_ptr(), weight.data_ptr(), wcode, out.data_ptr(), x.size(0),
+                                                 x.size(1), (int32_t)x.size(2), (int32_t)x.size(3), current_stream(x))
+                       : spice_depthwise_conv3x3_dilated(x.data_ptr(), weight.data_ptr(), wcode, out.data_ptr(),
+                                                         x.size(0), x.size(1), (int32_t)x.size(2), (int32_t)x.size(3),
+                                                         (int32_t)dilation, current_stream(x));
+    check_rc(rc, "spice_depthwise_conv3x3");
+    return out;
+}
+
+// The one operator with a second route: where hipBLASLt offers no scratch-free algorithm for a
+// problem size (SPICE_ERR_UNSUPPORTED), the same matrix product goes through at::bmm (rocBLAS).
+Tensor conv1x1_f16(const Tensor &x, const Tensor &weight2d) {
+    TORCH_CHECK_TYPE(x.scalar_type() == at::kHalf && weight2d.scalar_type() == at::kHalf,
+                     "conv1x1_f16: x and weight must be fp16");
+    TORCH_CHECK(x.is_cuda(), "x is on ", x.device(),
+                "; the MI355X path has no CPU implementation (move the tensor to a HIP device)");
+    TORCH_CHECK(weight2d.device() == x.device(), "conv1x1_f16: weight must be on x's device");
+    TORCH_CHECK_VALUE(x.dim() == 4 && weight2d.dim() == 2 && weight2d.size(1) == x.size(1) && x.is_contiguous() &&
+                          weight2d.is_contiguous(),
+                      "conv1x1_f16: x must be contiguous [N,Cin,H,W] and weight contiguous [Cout,Cin]");
+    const int64_t n = x.size(0), cin = x.size(1), h = x.size(2), w = x.size(3), cout = weight2d.size(0);
+    c10::DeviceGuard guard(x.device());
+    Tensor out = at::empty({n, cout, h, w}, x.options());
+    const int rc = spice_conv1x1_f16(x.data_ptr(), weight2d.data_ptr(), out.data_ptr(), n, cin, h * w, cout,
+                                     current_stream(x));
+    if (rc == SPICE_ERR_UNSUPPORTED)
+        return at::bmm(weight2d.unsqueeze(0).expand({n, cout, cin}), x.view({n, cin, h * w})).view({n, cout, h, w});
+    check_rc(rc, "spice_conv1x1_f16");
+    return out;
+}
+
+int64_t abi_version() { return spice_abi_version(); }
+
+}  // namespace
+
+TORCH_LIBRARY(spice, m) {
+    m.def("abi_version() -> int", &abi_version);
+    m.def("importance_run(Tensor[] weights, Tensor[] grads, Tensor(a!) scores, Tensor items, int n_items, int mode, "
+          "bool accumulate) -> ()", &importance_run);
+    m.def("importance_cols_run(Tensor[] weights, Tensor(a!) scores, Tensor(b!) partial, Tensor items, int n_items, "
+          "Tensor folds, int n_folds, int mode) -> ()", &importance_cols_run);
+    m.def("gather_run(Tensor[] srcs, Tensor(a!) dst, Tensor idx, Tensor items, int n_items) -> ()", &gather_run);
+    m.def("confusion_update(Tensor(a!) conf, Tensor preds, Tensor target, int num_classes, Tensor(b!) workspace) -> ()",
+          &confusion_update);
+    m.def("argmax_confusion_update(Tensor(a!) conf, Tensor logits, Tensor target, int num_classes, "
+          "Tensor(b!) workspace) -> ()", &argmax_confusion_update);
+    m.def("kdlite_forward(Tensor student, Tensor teacher, Tensor labels, float temperature, float alpha, "
+          "int ignore_index, float boundary_weight, bool confidence_weight, Tensor? class_weight, bool want_grad, "
+          "float coef_ce, float coef_kd, Tensor? upstream, Tensor(a!) workspace) -> (Tensor, Tensor)", &kdlite_forward);
+    m.def("scale_inplace(Tensor(a!) x, Tensor scale) -> ()", &scale_inplace);
+    m.def("upsample_bilinear(Tensor x, int out_h, int out_w, bool align_corners, float scale_h, float scale_w, "
+          "int out_dtype) -> Tensor", &upsample_bilinear);
+    m.def("bn_act(Tensor x, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, Tensor? residual, "
+          "bool relu) -> Tensor", &bn_act);
+    m.def("depthwise_conv3x3(Tensor x, Tensor weight, int dilation) -> Tensor", &depthwise_conv3x3);
+    m.def("conv1x1_f16(Tensor x, Tensor weight2d) -> Tensor", &conv1x1_f16);
+}

@@ -155,6 +155,8 @@ static int launch_up(const UpArgs &a, int64_t planes, bool vec, size_t lds, hipS
 
 }  // namespace spice
 
+SPICE_ENV_KNOB(knob_up_target_outputs, "SPICE_UP_TARGET_OUTPUTS", 0)  // tuning knob, read once
+
 extern "C" int spice_upsample_bilinear(const void *src, int32_t src_dtype, void *dst, int32_t dst_dtype,
                                        int64_t planes, int32_t in_h, int32_t in_w, int32_t out_h,
                                        int32_t out_w, int32_t align_corners, float scale_h, float scale_w,
@@ -183,8 +185,7 @@ extern "C" int spice_upsample_bilinear(const void *src, int32_t src_dtype, void 
         a.scale_w = scale_w > 0.0f ? 1.0f / scale_w : static_cast<float>(in_w) / static_cast<float>(out_w);
     }
     if (a.scale_h > 1.0f || a.scale_w > 1.0f) return SPICE_ERR_UNSUPPORTED;
-    int target = kUpTargetOutputs;
-    if (const char *e = getenv("SPICE_UP_TARGET_OUTPUTS")) target = atoi(e) > 0 ? atoi(e) : target;
+    const int target = knob_up_target_outputs() > 0 ? (int)knob_up_target_outputs() : kUpTargetOutputs;
     a.rows_per_block = static_cast<int>(target / out_w);
     if (a.rows_per_block < 1) a.rows_per_block = 1;
     if (a.rows_per_block > out_h) a.rows_per_block = out_h;

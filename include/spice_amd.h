@@ -35,6 +35,7 @@ extern "C" {
 #define SPICE_ERR_UNSUPPORTED 10002 /* shape outside what the kernels implement */
 #define SPICE_ERR_WORKSPACE 10003   /* workspace smaller than *_workspace_bytes() */
 #define SPICE_ERR_BLAS 10004        /* a hipBLASLt call failed */
+#define SPICE_ERR_STATIC_LIMIT 10005 /* input beyond the fixed scratch of spice_confusion_update_static */
 
 /* ABI version the library was built with (compare with SPICE_ABI_VERSION). */
 int spice_abi_version(void);
@@ -189,6 +190,24 @@ size_t spice_confusion_workspace_bytes(int64_t n_pixels, int32_t num_classes);
 int spice_confusion_update(const int64_t *preds, const int64_t *target, int64_t n_pixels,
                            int32_t num_classes, int64_t *conf, void *workspace,
                            size_t workspace_bytes, void *stream);
+
+/* The same update for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart
+ * in the reference.  The table of per-workgroup totals that spice_confusion_update keeps
+ * in the caller's workspace lives in a fixed 4 MiB + 4 KiB device array inside the
+ * library (one copy per GPU, held until the process ends); the call allocates and frees
+ * nothing.  Limits: num_classes <= 32 and n_pixels <= 2^40, SPICE_ERR_STATIC_LIMIT beyond
+ * them.  `invalid_count` (device int64, may be NULL) is incremented by the number of
+ * pixels with a valid target and a prediction outside [0,C).  The device the stream
+ * belongs to must be the current device.  The first call on a device looks up that
+ * device's copy of the array (hipGetSymbolAddress); make it before a graph capture
+ * begins.  All calls on one GPU share the array: calls that may overlap in time on one
+ * GPU (different streams, different threads) race and must be serialised by the caller.
+ * Nothing needs clearing between calls: every call overwrites the rows it later reads
+ * and returns the arrival counters to zero. */
+int spice_confusion_update_static(const int64_t *preds, const int64_t *target, int64_t n_pixels,
+                                  int32_t num_classes, int64_t *conf, int64_t *invalid_count,
+                                  void *stream);
 
 /* Same update with the arg-max fused in: preds = argmax over C of logits
  * [N,C,HW] (first maximum wins, as torch.argmax), never materialised.

@@ -15,6 +15,9 @@ extern "C" const char *spice_error_string(int code) {
             return "workspace smaller than the *_workspace_bytes() requirement";
         case SPICE_ERR_BLAS:
             return "a hipBLASLt call failed";
+        case SPICE_ERR_STATIC_LIMIT:
+            return "input exceeds the fixed scratch of the entry point that allocates nothing "
+                   "(spice_confusion_update_static: at most 32 classes and 2^40 pixels)";
         default:
             return hipGetErrorString(static_cast<hipError_t>(code));
     }

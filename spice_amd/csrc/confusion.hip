@@ -9,6 +9,8 @@
 // bit-exact and independent of scheduling.
 #include "common.h"
 
+#include <mutex>
+
 #include <hip/hip_fp16.h>
 
 namespace spice {
@@ -498,6 +500,51 @@ extern "C" int spice_confusion_update(const int64_t *preds, const int64_t *targe
         return SPICE_OK;
     }
     return confusion_update_on(preds, target, n_pixels, num_classes, conf, workspace, nullptr, st);
+}
+
+// ---- the same update for callers that cannot allocate -------------------------------------
+//
+// The scratch table lives in a file-scope device array instead of a caller workspace.  Each GPU
+// holds its own copy of the array at its own address; in host code the array's name is only a
+// stand-in, so the address is looked up once per device (with that device current) and that
+// pointer, never the name, is what the kernels receive.
+constexpr int kConfStaticMaxClasses = 32;
+constexpr size_t kConfStaticBytes =
+    kConfHeader + (size_t)kConfMaxBlocks * kConfStaticMaxClasses * kConfStaticMaxClasses * 4;  // 4 KiB + 4 MiB
+static __device__ __align__(256) unsigned char scratch[kConfStaticBytes];
+
+constexpr int kMaxDevices = 64;
+static std::mutex scratch_mutex;
+static void *scratch_ptr[kMaxDevices] = {};
+
+static int scratch_of_current_device(void **out) {
+    int dev = -1;
+    SPICE_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return SPICE_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(scratch_mutex);
+    if (scratch_ptr[dev] == nullptr) {
+        void *p = nullptr;
+        SPICE_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (p == nullptr) return SPICE_ERR_ARG;
+        scratch_ptr[dev] = p;
+    }
+    *out = scratch_ptr[dev];
+    return SPICE_OK;
+}
+
+extern "C" int spice_confusion_update_static(const int64_t *preds, const int64_t *target, int64_t n_pixels,
+                                             int32_t num_classes, int64_t *conf, int64_t *invalid_count,
+                                             void *stream) {
+    if (n_pixels < 0 || num_classes < 1) return SPICE_ERR_ARG;
+    if (num_classes > kConfStaticMaxClasses || n_pixels > kConfMaxPixels) return SPICE_ERR_STATIC_LIMIT;
+    if (n_pixels == 0) return SPICE_OK;
+    if (!preds || !target || !conf) return SPICE_ERR_ARG;
+    if (!aligned8(preds) || !aligned8(target) || !aligned8(conf) || !aligned8(invalid_count)) return SPICE_ERR_ARG;
+    void *dev_scratch = nullptr;
+    const int rc = scratch_of_current_device(&dev_scratch);
+    if (rc != SPICE_OK) return rc;
+    return confusion_update_on(preds, target, n_pixels, num_classes, conf, dev_scratch, invalid_count,
+                               static_cast<hipStream_t>(stream));
 }
 
 extern "C" int spice_argmax_confusion_update(const void *logits, int32_t logits_dtype,

@@ -145,6 +145,27 @@ void confusion_update(Tensor conf, const Tensor &preds, const Tensor &target, in
              "spice_confusion_update");
 }
 
+void confusion_update_static(Tensor conf, const Tensor &preds, const Tensor &target, int64_t num_classes,
+                             c10::optional<Tensor> invalid_count) {
+    check_conf(conf, num_classes);
+    check_dev(preds, "preds", at::kLong);
+    check_dev(target, "target", at::kLong);
+    check_same_device(conf, preds, "preds");
+    check_same_device(conf, target, "target");
+    TORCH_CHECK_VALUE(preds.numel() == target.numel(), "preds and target differ in element count");
+    int64_t *bad = nullptr;
+    if (invalid_count.has_value()) {
+        check_dev(*invalid_count, "invalid_count", at::kLong);
+        check_same_device(conf, *invalid_count, "invalid_count");
+        TORCH_CHECK_VALUE(invalid_count->numel() >= 1, "invalid_count must hold one int64");
+        bad = invalid_count->data_ptr<int64_t>();
+    }
+    c10::DeviceGuard guard(conf.device());
+    check_rc(spice_confusion_update_static(preds.data_ptr<int64_t>(), target.data_ptr<int64_t>(), preds.numel(),
+                                           (int32_t)num_classes, conf.data_ptr<int64_t>(), bad, current_stream(conf)),
+             "spice_confusion_update_static");
+}
+
 int32_t logits_code(const Tensor &t, const char *name) {
     switch (t.scalar_type()) {
         case at::kFloat: return 0;
@@ -345,6 +366,8 @@ TORCH_LIBRARY(spice, m) {
     m.def("gather_run(Tensor[] srcs, Tensor(a!) dst, Tensor idx, Tensor items, int n_items) -> ()", &gather_run);
     m.def("confusion_update(Tensor(a!) conf, Tensor preds, Tensor target, int num_classes, Tensor(b!) workspace) -> ()",
           &confusion_update);
+    m.def("confusion_update_static(Tensor(a!) conf, Tensor preds, Tensor target, int num_classes, "
+          "Tensor(b!)? invalid_count) -> ()", &confusion_update_static);
     m.def("argmax_confusion_update(Tensor(a!) conf, Tensor logits, Tensor target, int num_classes, "
           "Tensor(b!) workspace) -> ()", &argmax_confusion_update);
     m.def("kdlite_forward(Tensor student, Tensor teacher, Tensor labels, float temperature, float alpha, "

@@ -124,11 +124,10 @@ def kernel_table(dev):
         return lst[k[0] % len(lst)]
 
     row("importance_rows<L2> (DeepLabV3+-R50 conv weights)",
-        event_ms(lambda: plan.run(cyc(ws).data_ptr(), 0, score.data_ptr(), nat.IMP_L2, False), 20),
+        event_ms(lambda: plan.run([cyc(ws)], (), score, nat.IMP_L2, False), 20),
         plan.algorithmic_bytes(nat.IMP_L2))
     row("importance_rows<TAYLOR> (weights + grads, accumulate)",
-        event_ms(lambda: plan.run(cyc(ws).data_ptr(), gs[k[0] % 4].data_ptr(), score.data_ptr(),
-                                  nat.IMP_TAYLOR, True), 20),
+        event_ms(lambda: plan.run([cyc(ws)], [gs[k[0] % 4]], score, nat.IMP_TAYLOR, True), 20),
         plan.algorithmic_bytes(nat.IMP_TAYLOR))
     specs, idx, dpos, ipos = [], [], 0, 0
     for (o, i, kh, kw), off in zip(shapes, offs):
@@ -141,7 +140,7 @@ def kernel_table(dev):
     idx_t = torch.from_numpy(np.concatenate(idx)).to(dev)
     dsts = [torch.empty(dpos, device=dev) for _ in range(4)]
     row("gather (keep every 2nd out-channel of every conv)",
-        event_ms(lambda: gplan.run(cyc(ws).data_ptr(), dsts[k[0] % 4].data_ptr(), idx_t.data_ptr()), 20),
+        event_ms(lambda: gplan.run([cyc(ws)], dsts[k[0] % 4], idx_t), 20),
         gplan.algorithmic_bytes())
     del ws, gs, dsts
 

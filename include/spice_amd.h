@@ -251,7 +251,8 @@ typedef struct spice_gather_item {
     int32_t src_cols;
     int32_t inner;
     int32_t lanes;       /* reserved, 0 */
-    int32_t flags;       /* bit0: whole rows may move as 16-byte words; bit1: dst_off % 4 == 0 */
+    int32_t flags;       /* bit0: whole rows may move as 16-byte words; bit1: dst_off % 4 == 0;
+                            bit2: in-channel list with rows staged in LDS */
     int32_t pad_;
 } spice_gather_item;
 

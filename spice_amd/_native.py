@@ -15,6 +15,7 @@ import torch  # noqa: F401  (must precede the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libspice_amd.so")
+TORCH_LIB_PATH = os.path.join(_HERE, "lib", "libspice_torch.so")
 
 ABI_VERSION = 2
 ERR_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_BLAS, ERR_STATIC_LIMIT = 10001, 10002, 10003, 10004, 10005
@@ -129,6 +130,26 @@ def lib() -> ctypes.CDLL:
             f"{LIB_PATH} has ABI {handle.spice_abi_version()}, expected {ABI_VERSION}; rebuild it")
     _lib = handle
     return _lib
+
+
+_torch_ops = None
+
+
+def load_torch_ops():
+    """torch.ops.spice after loading libspice_torch.so (TORCH_LIBRARY registrations over the C ABI)."""
+    global _torch_ops
+    if _torch_ops is not None:
+        return _torch_ops
+    if not os.path.exists(TORCH_LIB_PATH):
+        raise NativeLibraryError(
+            f"{TORCH_LIB_PATH} is missing: build it with `make` at the repository root "
+            "(or __graft_entry__.build()); this package has no fallback compute path")
+    lib()  # the C ABI library first: the extension links against it
+    torch.ops.load_library(TORCH_LIB_PATH)
+    if int(torch.ops.spice.abi_version()) != ABI_VERSION:
+        raise NativeLibraryError(f"{TORCH_LIB_PATH} was built against another ABI version; rebuild it")
+    _torch_ops = torch.ops.spice
+    return _torch_ops
 
 
 def check(code: int, what: str) -> None:

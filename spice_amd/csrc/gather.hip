@@ -18,6 +18,84 @@ static int64_t gather_target_elems() {
     return (v >= 256 && v <= (1 << 22)) ? v : kGatherDefaultTargetElems;
 }
 
+// Items with an in-channel list whose kept source rows fit this many 32-bit words are staged in
+// LDS: whole source rows arrive with 16-byte loads (every 64-byte sector of a kept row holds kept
+// columns anyway when every second channel goes), the kept columns are picked out of LDS, and
+// the destination is written with 16-byte stores.
+constexpr int kGatherStageWords = 5120;   // 20 KB of source rows per workgroup
+constexpr int kGatherStageCols = 2048;    // 8 KB table of kept-column offsets
+constexpr size_t kGatherLdsBytes = (size_t)(kGatherStageWords + kGatherStageCols) * 4;
+constexpr int64_t kGatherStageTargetElems = 2048;  // destination words per staged item
+
+static int64_t gather_stage_target_elems() {
+    const char *e = getenv("SPICE_GATHER_STAGE_TARGET_ELEMS");  // tuning knob (host side only)
+    const long v = e ? atol(e) : 0;
+    return (v >= 256 && v <= (1 << 22)) ? v : kGatherStageTargetElems;
+}
+
+// One staged work item (flags bit2): rows and kept columns as described above.  Requirements, all
+// checked by the planner: 16-byte aligned source rows and destination rows, row_len % 4 == 0,
+// n_rows * src_cols * inner <= kGatherStageWords, dst_cols <= kGatherStageCols.
+__device__ __forceinline__ void gather_staged(const spice_gather_item &it, const unsigned *__restrict__ src,
+                                              unsigned *__restrict__ dst, const long long *__restrict__ idx_out,
+                                              const long long *__restrict__ idx_in, unsigned *lds) {
+    const int tid = threadIdx.x;
+    const int inner = it.inner;
+    const int row_len = it.dst_cols * inner;
+    const int src_stride = it.src_cols * inner;
+    unsigned *rows = lds;
+    int *coltab = reinterpret_cast<int *>(lds + kGatherStageWords);
+    for (int i = tid; i < it.dst_cols; i += kGatherThreads) coltab[i] = (int)idx_in[i] * inner;
+    // source rows -> LDS, flat over (row, 16-byte chunk)
+    const int stride4 = src_stride >> 2;
+    const int total4 = it.n_rows * stride4;
+    const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
+    uint4 *rows4 = reinterpret_cast<uint4 *>(rows);
+    int f0 = tid;
+    for (; f0 + 3 * kGatherThreads < total4; f0 += 4 * kGatherThreads) {
+        long long so[4];
+        int col[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = f0 + u * kGatherThreads;
+            const int row = f / stride4;
+            col[u] = f - row * stride4;
+            so[u] = idx_out ? idx_out[row] : (long long)(it.row0 + row);
+        }
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ld_stream16(src4 + (so[u] * stride4 + col[u]));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rows4[f0 + u * kGatherThreads] = v[u];
+    }
+    for (; f0 < total4; f0 += kGatherThreads) {
+        const int row = f0 / stride4;
+        const long long so = idx_out ? idx_out[row] : (long long)(it.row0 + row);
+        rows4[f0] = ld_stream16(src4 + (so * stride4 + (f0 - row * stride4)));
+    }
+    __syncthreads();
+    // kept columns out of LDS, four consecutive destination words per lane (never across a row)
+    const int total = it.n_rows * row_len;
+    uint4 *dst4 = reinterpret_cast<uint4 *>(dst);
+    for (int e0 = tid * 4; e0 < total; e0 += 4 * kGatherThreads) {
+        const int row = e0 / row_len;
+        const int rem = e0 - row * row_len;
+        int i = inner == 1 ? rem : rem / inner;
+        int k = rem - i * inner;
+        const unsigned *r = rows + row * src_stride;
+        unsigned v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] = r[coltab[i] + k];
+            if (++k == inner) {
+                k = 0;
+                ++i;
+            }
+        }
+        st_stream16(dst4 + (e0 >> 2), make_uint4(v[0], v[1], v[2], v[3]));
+    }
+}
+
 // Element gather of one work item: the same flat walk over the destination as the whole-row
 // path, four consecutive 32-bit words per lane and two such quads per pass, so stores stay
 // contiguous (one 16-byte store per lane where the item's destination is 16-byte aligned) while
@@ -91,6 +169,7 @@ __global__ __launch_bounds__(kGatherThreads) void gather_kernel(
     const unsigned *__restrict__ src_base, unsigned *__restrict__ dst_base,
     const long long *__restrict__ idx_base, const spice_gather_item *__restrict__ items,
     int bases_vec_ok) {
+    extern __shared__ unsigned gather_lds[];
     const spice_gather_item it = items[blockIdx.x];
     const int tid = threadIdx.x;
     const int row_len = it.dst_cols * it.inner;
@@ -138,6 +217,10 @@ __global__ __launch_bounds__(kGatherThreads) void gather_kernel(
         }
         return;
     }
+    if (idx_in != nullptr && bases_vec_ok && (it.flags & 4)) {
+        gather_staged(it, src, dst, idx_out, idx_in, gather_lds);
+        return;
+    }
     // Element gather (an in-channel list is present, or the layout rules out 16-byte moves).
     const bool st4 = bases_vec_ok && (it.flags & 2);
     if (idx_out) {
@@ -174,10 +257,14 @@ extern "C" int64_t spice_gather_plan(const spice_gather_desc *tensors, int32_t n
                          (d.dst_off % 4 == 0);
         // rows per item: the kernel walks an item's destination as one contiguous range, so any
         // row count will do; small items keep many workgroups in flight
-        int64_t rpi = target / row_len;
+        // staged path: in-channel list, 16-byte aligned source and destination rows, rows that fit LDS
+        const bool stage = d.idx_in_off >= 0 && (row_len % 4 == 0) && (src_stride % 4 == 0) && (d.src_off % 4 == 0) &&
+                           (d.dst_off % 4 == 0) && src_stride <= kGatherStageWords && d.dst_cols <= kGatherStageCols;
+        int64_t rpi = (stage ? gather_stage_target_elems() : target) / row_len;
+        if (stage && rpi > kGatherStageWords / src_stride) rpi = kGatherStageWords / src_stride;
         if (rpi < 1) rpi = 1;
         const int64_t n_it = ceil_div(d.dst_rows, rpi);
-        rpi = ceil_div(d.dst_rows, n_it);
+        rpi = ceil_div(d.dst_rows, n_it);  // never larger than before: the LDS bound still holds
         for (int64_t r0 = 0; r0 < d.dst_rows; r0 += rpi, ++n) {
             if (items == nullptr || n >= capacity) continue;
             spice_gather_item &it = items[n];
@@ -191,7 +278,7 @@ extern "C" int64_t spice_gather_plan(const spice_gather_desc *tensors, int32_t n
             it.src_cols = (int32_t)d.src_cols;
             it.inner = (int32_t)d.inner;
             it.lanes = 0;
-            it.flags = (vec ? 1 : 0) | (((d.dst_off + r0 * row_len) % 4 == 0) ? 2 : 0);
+            it.flags = (vec ? 1 : 0) | (((d.dst_off + r0 * row_len) % 4 == 0) ? 2 : 0) | (stage ? 4 : 0);
             it.pad_ = 0;
         }
     }
@@ -206,7 +293,7 @@ extern "C" int spice_gather_run(const float *src_base, float *dst_base, const in
     if ((reinterpret_cast<uintptr_t>(src_base) & 3u) || (reinterpret_cast<uintptr_t>(dst_base) & 3u))
         return SPICE_ERR_ARG;
     const int vec_ok = aligned16(src_base) && aligned16(dst_base);
-    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)n_items), dim3(kGatherThreads), 0,
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)n_items), dim3(kGatherThreads), kGatherLdsBytes,
                        static_cast<hipStream_t>(stream), reinterpret_cast<const unsigned *>(src_base),
                        reinterpret_cast<unsigned *>(dst_base),
                        reinterpret_cast<const long long *>(idx_base), d_items, vec_ok);

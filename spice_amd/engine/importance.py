@@ -89,7 +89,7 @@ class MagnitudeImportance(Importance):
             weights = [c.weight.detach() for c in col_mods]
             for w in weights:
                 nat.require_device_tensor(w, "weight", torch.float32)
-            base, w_offs = ops._relative_offsets(weights, "weights")
+            _, w_offs = ops._relative_offsets(weights, "weights")
             layers, pos = [], 0
             for c, wo in zip(col_mods, w_offs):
                 cin = c.weight.shape[1]
@@ -99,7 +99,7 @@ class MagnitudeImportance(Importance):
                 pos += cin
             plan = ops.ColsPlan(layers, device)
             cols = torch.empty(max(pos, 1), dtype=torch.float32, device=device)
-            plan.run(base, cols.data_ptr(), self.mode)
+            plan.run(weights, cols, self.mode)
             pieces.append(cols)
         host = torch.cat(pieces).cpu().numpy()  # the step's single device->host copy
         n_rows = flat.numel()

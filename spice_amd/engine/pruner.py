@@ -122,7 +122,8 @@ class SliceJob:
             if t.dtype != torch.float32 or not t.is_contiguous() or t.device.type != "cuda":
                 raise RuntimeError("channel slicing needs contiguous fp32 tensors on a HIP device")
         self.device = srcs[0].device
-        self.src_base, src_offs = ops._relative_offsets(srcs, "tensors to slice")
+        self.srcs = srcs
+        _, src_offs = ops._relative_offsets(srcs, "tensors to slice")
         specs, self.shapes, self.dst_offs = [], [], []
         ipos, dpos = idx_start, 0
         first = {}  # the gradient entries reuse the index arrays of their parameter
@@ -166,7 +167,7 @@ class SliceJob:
         if self.plan is None:
             self.build()
         dst = torch.empty(max(self.dst_elems, 1), dtype=torch.float32, device=self.device)
-        self.plan.run(self.src_base, dst.data_ptr(), self.idx.data_ptr())
+        self.plan.run(self.srcs, dst, self.idx)
         if keep_undo:
             self._undo = ([(o, a, getattr(o, a)) for o, a, _, _ in self.entries],
                           [(m, {k: getattr(m, k) for k in upd}) for m, upd in self.attr_updates],

@@ -1,8 +1,10 @@
 """Tensor-level entry points of the MI355X hot path.
 
-Each function validates its torch tensors, hands raw device pointers and the current
-HIP stream to the C ABI (spice_amd/_native.py) and returns torch tensors.  Nothing
-here computes on the CPU and nothing falls back to stock torch ops.
+Every launch goes through `torch.ops.spice.*`, the thin torch C++ extension
+(spice_amd/csrc/torch_ext.cpp -> lib/libspice_torch.so) that checks the tensors, takes torch's
+current HIP stream and calls the C ABI of libspice_amd.so.  Host-only planning (work-item
+tables) calls the C ABI directly (spice_amd/_native.py).  Nothing here computes on the CPU and
+nothing falls back to stock torch ops.
 """
 from __future__ import annotations
 
@@ -13,6 +15,17 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _native as nat
+
+_ops = None
+
+
+def spice_ops():
+    """torch.ops.spice, with lib/libspice_torch.so loaded; raises NativeLibraryError if it is missing."""
+    global _ops
+    if _ops is None:
+        nat.lib()
+        _ops = nat.load_torch_ops()
+    return _ops
 
 # --------------------------------------------------------------------------------------
 # work-item tables
@@ -59,11 +72,12 @@ class RowsPlan:
         self.weight_elems = sum(l.rows * l.row_len for l in self.layers)
         self.score_elems = sum(l.rows for l in self.layers)
 
-    def run(self, w_base: int, g_base: int, score_base: int, mode: int, accumulate: bool) -> None:
-        rc = nat.lib().spice_importance_run(w_base, g_base, score_base, self.items.data_ptr(),
-                                            self.n_items, mode, int(bool(accumulate)),
-                                            nat.current_stream_ptr(self.device))
-        nat.check(rc, "spice_importance_run")
+    def run(self, weights: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], scores: torch.Tensor,
+            mode: int, accumulate: bool) -> None:
+        """One launch over every planned layer.  The plan's offsets count from the lowest address
+        among `weights` (and among `grads` in Taylor mode; ignored otherwise)."""
+        spice_ops().importance_run(list(weights), list(grads), scores, self.items, self.n_items, mode,
+                                   bool(accumulate))
 
     def algorithmic_bytes(self, mode: int) -> int:
         """Bytes one launch must move: every weight (and gradient) element once plus the scores."""
@@ -105,12 +119,9 @@ class ColsPlan:
         self.folds = _upload_items(folds, self.n_folds, self.device)
         self.partial = torch.empty(max(int(part.value), 4), dtype=torch.float32, device=self.device)
 
-    def run(self, w_base: int, score_base: int, mode: int) -> None:
-        rc = nat.lib().spice_importance_cols_run(w_base, score_base, self.partial.data_ptr(),
-                                                 self.items.data_ptr(), self.n_items,
-                                                 self.folds.data_ptr(), self.n_folds, mode,
-                                                 nat.current_stream_ptr(self.device))
-        nat.check(rc, "spice_importance_cols_run")
+    def run(self, weights: Sequence[torch.Tensor], scores: torch.Tensor, mode: int) -> None:
+        spice_ops().importance_cols_run(list(weights), scores, self.partial, self.items, self.n_items,
+                                        self.folds, self.n_folds, mode)
 
 
 def _relative_offsets(tensors: Sequence[torch.Tensor], what: str) -> Tuple[int, List[int]]:
@@ -126,7 +137,7 @@ def _relative_offsets(tensors: Sequence[torch.Tensor], what: str) -> Tuple[int, 
     return base, offs
 
 
-_rows_plan_cache: Dict[tuple, Tuple[RowsPlan, int, List[int]]] = {}
+_rows_plan_cache: Dict[tuple, Tuple[RowsPlan, List[int]]] = {}
 
 
 def channel_importance(weights: Sequence[torch.Tensor], mode: int,
@@ -171,9 +182,9 @@ def channel_importance(weights: Sequence[torch.Tensor], mode: int,
         plan = RowsPlan(layers, device)
         if len(_rows_plan_cache) > 64:
             _rows_plan_cache.clear()
-        _rows_plan_cache[key] = (plan, w_base, g_base, out_offs)
+        _rows_plan_cache[key] = (plan, out_offs)
         hit = _rows_plan_cache[key]
-    plan, w_base, g_base, out_offs = hit
+    plan, out_offs = hit
     if out is None:
         if accumulate:
             raise ValueError("channel_importance: accumulate=True needs an existing `out`")
@@ -182,7 +193,7 @@ def channel_importance(weights: Sequence[torch.Tensor], mode: int,
         nat.require_device_tensor(out, "out", torch.float32)
         if out.numel() != plan.score_elems:
             raise ValueError(f"out has {out.numel()} elements, expected {plan.score_elems}")
-    plan.run(w_base, g_base, out.data_ptr(), mode, accumulate)
+    plan.run(weights, grads if mode == nat.IMP_TAYLOR else (), out, mode, accumulate)
     return out, out_offs
 
 
@@ -192,9 +203,14 @@ def channel_importance(weights: Sequence[torch.Tensor], mode: int,
 _workspaces: Dict[tuple, torch.Tensor] = {}
 
 
+def _dev_index(device) -> int:
+    device = torch.device(device)
+    return torch.cuda.current_device() if device.index is None else device.index
+
+
 def _workspace(kind: str, device: torch.device, nbytes: int) -> torch.Tensor:
     """Per (kind, device, stream) scratch buffer, zero-initialised once."""
-    key = (kind, device.index, nat.current_stream_ptr(device))
+    key = (kind, _dev_index(device), nat.current_stream_ptr(device))
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
@@ -204,22 +220,13 @@ def _workspace(kind: str, device: torch.device, nbytes: int) -> torch.Tensor:
 
 def confusion_update(conf: torch.Tensor, preds: torch.Tensor, target: torch.Tensor,
                      num_classes: int) -> None:
-    """conf[t, p] += 1 for every pixel with 0 <= t < num_classes (in place, int64)."""
-    nat.require_device_tensor(conf, "conf", torch.int64)
-    nat.require_device_tensor(preds, "preds", torch.int64)
-    nat.require_device_tensor(target, "target", torch.int64)
-    if conf.shape != (num_classes, num_classes):
-        raise ValueError(f"conf must be [{num_classes},{num_classes}], got {tuple(conf.shape)}")
-    if preds.numel() != target.numel():
-        raise ValueError("preds and target differ in element count")
-    L = nat.lib()
-    n = preds.numel()
+    """conf[t, p] += 1 for every pixel with 0 <= t < num_classes (in place, int64).
+    Device, dtype, contiguity and shape are checked by the extension."""
+    if not conf.is_cuda:
+        nat.require_device_tensor(conf, "conf", torch.int64)
     ws = _workspace("conf%d" % num_classes, conf.device,
-                    L.spice_confusion_workspace_bytes(n, num_classes))
-    rc = L.spice_confusion_update(preds.data_ptr(), target.data_ptr(), n, num_classes,
-                                  conf.data_ptr(), ws.data_ptr(), ws.numel(),
-                                  nat.current_stream_ptr(conf.device))
-    nat.check(rc, "spice_confusion_update")
+                    nat.lib().spice_confusion_workspace_bytes(preds.numel(), num_classes))
+    spice_ops().confusion_update(conf, preds, target, num_classes, ws)
 
 
 _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
@@ -228,25 +235,11 @@ _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 def argmax_confusion_update(conf: torch.Tensor, logits: torch.Tensor, target: torch.Tensor,
                             num_classes: int) -> None:
     """confusion_update(conf, logits.argmax(1), target) without materialising the arg-max."""
-    nat.require_device_tensor(conf, "conf", torch.int64)
-    nat.require_device_tensor(target, "target", torch.int64)
-    if logits.dtype not in _DTYPE_CODE:
-        raise TypeError(f"logits dtype {logits.dtype} not supported")
-    nat.require_device_tensor(logits, "logits", logits.dtype)
-    if logits.dim() < 2 or logits.shape[1] != num_classes:
-        raise ValueError("logits must be [N, num_classes, ...]")
-    n = int(logits.shape[0])
-    hw = logits.numel() // max(n * num_classes, 1)
-    if target.numel() != n * hw:
-        raise ValueError("target must have N*H*W elements")
-    L = nat.lib()
+    if not conf.is_cuda:
+        nat.require_device_tensor(conf, "conf", torch.int64)
     ws = _workspace("conf%d" % num_classes, conf.device,
-                    L.spice_confusion_workspace_bytes(n * hw, num_classes))
-    rc = L.spice_argmax_confusion_update(logits.data_ptr(), _DTYPE_CODE[logits.dtype],
-                                         target.data_ptr(), n, hw, num_classes, conf.data_ptr(),
-                                         ws.data_ptr(), ws.numel(),
-                                         nat.current_stream_ptr(conf.device))
-    nat.check(rc, "spice_argmax_confusion_update")
+                    nat.lib().spice_confusion_workspace_bytes(target.numel(), num_classes))
+    spice_ops().argmax_confusion_update(conf, logits, target, num_classes, ws)
 
 
 def invalid_prediction_count(device: torch.device, num_classes: int) -> int:
@@ -254,8 +247,7 @@ def invalid_prediction_count(device: torch.device, num_classes: int) -> int:
 
     Synchronises.  The reference fails on such input; here they are skipped and counted.
     """
-    key = ("conf%d" % num_classes, torch.device(device).index,
-           nat.current_stream_ptr(torch.device(device)))
+    key = ("conf%d" % num_classes, _dev_index(device), nat.current_stream_ptr(torch.device(device)))
     ws = _workspaces.get(key)
     if ws is None:
         return 0
@@ -279,37 +271,19 @@ def kdlite_forward(student: torch.Tensor, teacher: torch.Tensor, labels: torch.T
     (alpha, 1-alpha), i.e. d(total)/d(student).  `upstream` (device, 3 floats: incoming
     gradients of total/ce/kd) overrides coef on the device.
     """
-    nat.require_device_tensor(student, "student_logits", torch.float32)
-    nat.require_device_tensor(teacher, "teacher_logits", torch.float32)
-    nat.require_device_tensor(labels, "labels", torch.int64)
-    if student.dim() != 4 or teacher.shape != student.shape:
+    if not student.is_cuda:
+        nat.require_device_tensor(student, "student_logits", torch.float32)
+    if student.dim() != 4:
         raise ValueError("student/teacher logits must both be [N,C,H,W]")
-    n, c, h, w = (int(x) for x in student.shape)
-    if tuple(labels.shape) != (n, h, w):
-        raise ValueError(f"labels must be [{n},{h},{w}], got {tuple(labels.shape)}")
-    if class_weight is not None:
-        nat.require_device_tensor(class_weight, "class_weight", torch.float32)
-        if class_weight.numel() != c:
-            raise ValueError("class_weight must have C elements")
-    L = nat.lib()
+    n, c, h, w = student.shape
     dev = student.device
-    ws = _workspace("kdlite", dev, L.spice_kdlite_workspace_bytes(n, c, h, w))
-    out3 = torch.empty(3, dtype=torch.float32, device=dev)
-    grad = torch.empty_like(student) if want_grad else None
-    params = nat.KdliteParams(float(temperature), float(alpha), float(boundary_weight),
-                              int(bool(confidence_weight)), int(ignore_index),
-                              class_weight.data_ptr() if class_weight is not None else None)
+    ws = _workspace("kdlite", dev, nat.lib().spice_kdlite_workspace_bytes(n, c, h, w))
     cce, ckd = coef if coef is not None else (float(alpha), 1.0 - float(alpha))
-    if upstream is not None:
-        nat.require_device_tensor(upstream, "upstream", torch.float32)
-        if upstream.numel() != 3:
-            raise ValueError("upstream must have 3 elements")
-    rc = L.spice_kdlite_forward(student.data_ptr(), teacher.data_ptr(), labels.data_ptr(), n, c, h,
-                                w, ctypes.byref(params), out3.data_ptr(),
-                                grad.data_ptr() if grad is not None else None, cce, ckd,
-                                upstream.data_ptr() if upstream is not None else None,
-                                ws.data_ptr(), ws.numel(), nat.current_stream_ptr(dev))
-    nat.check(rc, "spice_kdlite_forward")
+    out3, grad = spice_ops().kdlite_forward(student, teacher, labels, float(temperature), float(alpha),
+                                            int(ignore_index), float(boundary_weight), bool(confidence_weight),
+                                            class_weight, bool(want_grad), cce, ckd, upstream, ws)
+    if not want_grad:
+        grad = None
     sums = ws[16:80].view(torch.float64)
     return out3, grad, sums
 
@@ -317,17 +291,13 @@ def kdlite_forward(student: torch.Tensor, teacher: torch.Tensor, labels: torch.T
 def kdlite_bad_label_count(device: torch.device) -> int:
     """Labels seen so far (this device and stream) that were neither ignore_index nor in [0,C)."""
     device = torch.device(device)
-    ws = _workspaces.get(("kdlite", device.index, nat.current_stream_ptr(device)))
+    ws = _workspaces.get(("kdlite", _dev_index(device), nat.current_stream_ptr(device)))
     return 0 if ws is None else int(ws[:8].view(torch.int64).item())
 
 
 def scale_inplace(x: torch.Tensor, scale: torch.Tensor) -> None:
     """x *= scale (a device scalar); a no-op on the device when scale == 1."""
-    nat.require_device_tensor(x, "x", torch.float32)
-    nat.require_device_tensor(scale, "scale", torch.float32)
-    rc = nat.lib().spice_scale_inplace(x.data_ptr(), x.numel(), scale.data_ptr(),
-                                       nat.current_stream_ptr(x.device))
-    nat.check(rc, "spice_scale_inplace")
+    spice_ops().scale_inplace(x, scale)
 
 
 # --------------------------------------------------------------------------------------
@@ -370,10 +340,10 @@ class GatherPlan:
         self.index_elems = sum((s.dst_rows if s.idx_out_off >= 0 else 0) +
                                (s.dst_cols if s.idx_in_off >= 0 else 0) for s in self.specs)
 
-    def run(self, src_base: int, dst_base: int, idx_base: int) -> None:
-        rc = nat.lib().spice_gather_run(src_base, dst_base, idx_base, self.items.data_ptr(),
-                                        self.n_items, nat.current_stream_ptr(self.device))
-        nat.check(rc, "spice_gather_run")
+    def run(self, srcs: Sequence[torch.Tensor], dst: torch.Tensor, idx: torch.Tensor) -> None:
+        """One launch for every planned tensor.  The plan's source offsets count from the lowest
+        address among `srcs`, destination offsets from `dst`, index offsets from `idx`."""
+        spice_ops().gather_run(list(srcs), dst, idx, self.items, self.n_items)
 
     def algorithmic_bytes(self) -> int:
         return 8 * self.moved_elems + 8 * self.index_elems
@@ -403,7 +373,7 @@ def gather_channels(src: torch.Tensor, keep_out: Optional[torch.Tensor],
         shape[1] = d_cols
     dst = torch.empty(shape, dtype=torch.float32, device=src.device)
     plan = GatherPlan([GatherSpec(0, 0, o_off, i_off, d_rows, d_cols, cols, max(inner, 1))], src.device)
-    plan.run(src.data_ptr(), dst.data_ptr(), idx.data_ptr())
+    plan.run([src], dst, idx)
     return dst
 
 
@@ -430,12 +400,7 @@ def upsample_bilinear(x: torch.Tensor, size: Optional[Tuple[int, int]] = None,
     out_dtype = out_dtype or x.dtype
     if out_dtype not in (torch.float32, torch.float16):
         raise TypeError(f"upsample_bilinear: output dtype {out_dtype} not supported")
-    out = torch.empty(n, c, oh, ow, dtype=out_dtype, device=x.device)
-    rc = nat.lib().spice_upsample_bilinear(x.data_ptr(), _DTYPE_CODE[x.dtype], out.data_ptr(), _DTYPE_CODE[out_dtype],
-                                           n * c, h, w, oh, ow, 1 if align_corners else 0, sh, sw,
-                                           nat.current_stream_ptr(x.device))
-    nat.check(rc, "spice_upsample_bilinear")
-    return out
+    return spice_ops().upsample_bilinear(x, oh, ow, bool(align_corners), sh, sw, _DTYPE_CODE[out_dtype])
 
 
 def bn_act_supported(x: torch.Tensor) -> bool:
@@ -448,42 +413,17 @@ def bn_act_supported(x: torch.Tensor) -> bool:
     return x.dtype == torch.float16 and (x.shape[2] * x.shape[3]) % 2 == 0
 
 
-_raw_stream = torch._C._cuda_getCurrentRawStream
 _bn_fn = None
 
 
 def bn_act(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
            eps: float, residual: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
     """relu?(batch_norm(x, running statistics) [+ residual]) in one launch; a new tensor of x's dtype.
-    Called ~60 times per forward of a ResNet-50 model, so the checks are kept to attribute reads."""
+    Called ~60 times per forward of a ResNet-50 model: the argument checks are the extension's."""
     global _bn_fn
     if _bn_fn is None:
-        _bn_fn = nat.lib().spice_bn_act
-    dt = x.dtype
-    code = 0 if dt == torch.float32 else 1 if dt == torch.float16 else -1
-    if code < 0:
-        raise TypeError(f"bn_act: dtype {dt} not supported")
-    if not x.is_cuda:
-        nat.require_device_tensor(x, "x", dt)
-    if x.dim() != 4 or not x.is_contiguous():
-        raise ValueError("bn_act: x must be a contiguous [N, C, H, W] tensor")
-    n, c, h, w = x.shape
-    for t in (mean, var, weight, bias):
-        if t.dtype != torch.float32 or t.device != x.device or t.numel() != c or not t.is_contiguous():
-            raise TypeError(f"bn_act: the four parameter vectors must be contiguous fp32 [{c}] on {x.device}")
-    res_ptr = None
-    if residual is not None:
-        if residual.shape != x.shape:
-            raise ValueError("bn_act: residual must have x's shape")
-        if residual.dtype != dt or residual.device != x.device or not residual.is_contiguous():
-            raise TypeError("bn_act: residual must be contiguous, of x's dtype and on x's device")
-        res_ptr = residual.data_ptr()
-    out = torch.empty_like(x)
-    rc = _bn_fn(x.data_ptr(), res_ptr, out.data_ptr(), code, mean.data_ptr(), var.data_ptr(), weight.data_ptr(),
-                bias.data_ptr(), eps, n, c, h * w, 1 if relu else 0, _raw_stream(x.device.index))
-    if rc:
-        nat.check(rc, "spice_bn_act")
-    return out
+        _bn_fn = spice_ops().bn_act
+    return _bn_fn(x, mean, var, weight, bias, eps, residual, relu)
 
 
 def depthwise_conv3x3_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
@@ -497,23 +437,7 @@ def depthwise_conv3x3(x: torch.Tensor, weight: torch.Tensor, dilation: int = 1) 
     """conv2d(x, weight, stride=1, padding=dilation, dilation=dilation, groups=C) for fp16 x.
     dilation 1: exact sums, one rounding; dilation a multiple of 4: fp32 sums in tap order (what
     torch's own depthwise kernel, which serves those calls, computes)."""
-    nat.require_device_tensor(x, "x", torch.float16)
-    if weight.dtype not in (torch.float16, torch.float32):
-        raise TypeError(f"depthwise_conv3x3: weight dtype {weight.dtype} not supported")
-    nat.require_device_tensor(weight, "weight", weight.dtype)
-    if x.dim() != 4 or tuple(weight.shape) != (x.shape[1], 1, 3, 3):
-        raise ValueError("depthwise_conv3x3: x must be [N,C,H,W] and weight [C,1,3,3]")
-    n, c, h, w = x.shape
-    out = torch.empty_like(x)
-    code = 0 if weight.dtype == torch.float32 else 1
-    if dilation == 1:
-        rc = nat.lib().spice_depthwise_conv3x3(x.data_ptr(), weight.data_ptr(), code, out.data_ptr(), n, c, h, w,
-                                               _raw_stream(x.device.index))
-    else:
-        rc = nat.lib().spice_depthwise_conv3x3_dilated(x.data_ptr(), weight.data_ptr(), code, out.data_ptr(), n, c, h, w,
-                                                       int(dilation), _raw_stream(x.device.index))
-    nat.check(rc, "spice_depthwise_conv3x3")
-    return out
+    return spice_ops().depthwise_conv3x3(x, weight, int(dilation))
 
 
 _conv1x1_fn = None
@@ -525,21 +449,5 @@ def conv1x1_f16(x: torch.Tensor, weight2d: torch.Tensor) -> torch.Tensor:
     scratch-free algorithm for a size the product goes through torch.bmm (rocBLAS)."""
     global _conv1x1_fn
     if _conv1x1_fn is None:
-        _conv1x1_fn = nat.lib().spice_conv1x1_f16
-    if x.dtype != torch.float16 or weight2d.dtype != torch.float16:
-        raise TypeError("conv1x1_f16: x and weight must be fp16")
-    if not x.is_cuda or weight2d.device != x.device:
-        nat.require_device_tensor(x, "x", torch.float16)
-        raise RuntimeError("conv1x1_f16: weight must be on x's device")
-    if x.dim() != 4 or weight2d.dim() != 2 or weight2d.shape[1] != x.shape[1] or not x.is_contiguous() \
-            or not weight2d.is_contiguous():
-        raise ValueError("conv1x1_f16: x must be contiguous [N,Cin,H,W] and weight contiguous [Cout,Cin]")
-    n, cin, h, w = x.shape
-    cout = weight2d.shape[0]
-    out = torch.empty((n, cout, h, w), dtype=torch.float16, device=x.device)
-    rc = _conv1x1_fn(x.data_ptr(), weight2d.data_ptr(), out.data_ptr(), n, cin, h * w, cout, _raw_stream(x.device.index))
-    if rc == nat.ERR_UNSUPPORTED:
-        return torch.bmm(weight2d.expand(n, -1, -1), x.view(n, cin, h * w)).view(n, cout, h, w)
-    if rc:
-        nat.check(rc, "spice_conv1x1_f16")
-    return out
+        _conv1x1_fn = spice_ops().conv1x1_f16
+    return _conv1x1_fn(x, weight2d)

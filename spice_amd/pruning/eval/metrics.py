@@ -19,9 +19,16 @@ class SegmentationMetrics:
         self.num_classes = num_classes
         self.device = device
         self.conf = torch.zeros(num_classes, num_classes, dtype=torch.int64, device=device)
+        self._bad_base = self._bad_count()
+
+    def _bad_count(self) -> int:
+        # the counter is shared by every user of this device and stream and only ever grows:
+        # this object reports what was added since its last reset
+        return ops.invalid_prediction_count(self.conf.device, self.num_classes) if self.conf.is_cuda else 0
 
     def reset(self):
         self.conf.zero_()
+        self._bad_base = self._bad_count()
 
     def update(self, predictions: torch.Tensor, targets: torch.Tensor):
         """predictions, targets: class indices [B,H,W]; targets outside [0,C) are skipped."""
@@ -33,7 +40,7 @@ class SegmentationMetrics:
                                     self.num_classes)
 
     def compute_metrics(self) -> Dict[str, Any]:
-        bad = ops.invalid_prediction_count(self.conf.device, self.num_classes)
+        bad = self._bad_count() - self._bad_base
         if bad:
             raise RuntimeError(f"{bad} predictions were outside [0, {self.num_classes})")
         m = self.conf.cpu().numpy().astype(np.float64)

@@ -312,7 +312,7 @@ def test_in_channel_importance(dev):
     plan = ops.ColsPlan(layers, dev)
     for mode, p in ((nat.IMP_L1, 1), (nat.IMP_L2, 2)):
         out = torch.empty(opos, dtype=torch.float32, device=dev)
-        plan.run(flat.data_ptr(), out.data_ptr(), mode)
+        plan.run([flat], out, mode)
         got = out.cpu().numpy()
         for (w, _), lay in zip(pairs, layers):
             exact = oi.magnitude_cols_f64(w, p)
@@ -367,7 +367,7 @@ def test_gather_whole_model_one_launch(dev):
     plan = ops.GatherPlan(specs, dev)
     dst = torch.zeros(dpos, dtype=torch.float32, device=dev)
     idx = torch.from_numpy(np.concatenate(idx_parts)).to(dev)
-    plan.run(src.data_ptr(), dst.data_ptr(), idx.data_ptr())
+    plan.run([src], dst, idx)
     out = dst.cpu().numpy()
     for spec, ref in zip(specs, refs):
         got = out[spec.dst_off: spec.dst_off + ref.size].reshape(ref.shape)
@@ -429,7 +429,7 @@ def test_gather_unaligned_offsets_and_odd_rows(dev):
     guard = np.float32(-7.25)
     dst = torch.full((dpos + 8,), float(guard), dtype=torch.float32, device=dev)
     idx = torch.from_numpy(np.concatenate(idx_parts)).to(dev)
-    plan.run(torch.from_numpy(src).to(dev).data_ptr(), dst.data_ptr(), idx.data_ptr())
+    plan.run([torch.from_numpy(src).to(dev)], dst, idx)
     out = dst.cpu().numpy()
     written = np.zeros(out.shape, dtype=bool)
     for spec, ref in zip(specs, refs):

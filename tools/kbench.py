@@ -72,7 +72,7 @@ def main():
             for tgt in args.imp_targets.split(","):
                 os.environ["SPICE_IMP_TARGET_ELEMS"] = tgt
                 pl = ops.RowsPlan(layers, dev)
-                fns = [lambda w=w: pl.run(w.data_ptr(), 0, sc_t.data_ptr(), nat.IMP_L2, False) for w in w_t]
+                fns = [lambda w=w: pl.run([w], (), sc_t, nat.IMP_L2, False) for w in w_t]
                 report(f"importance_l2 target={tgt} ({pl.n_items} items)", timed(fns, args.iters), pl.algorithmic_bytes(nat.IMP_L2))
             os.environ.pop("SPICE_IMP_TARGET_ELEMS")
             del w_t
@@ -81,10 +81,10 @@ def main():
         score = torch.zeros(opos, device=dev)
         if want("importance"):
             for mode, nm in ((nat.IMP_L2, "importance_l2"), (nat.IMP_L1, "importance_l1")):
-                fns = [lambda w=w: plan.run(w.data_ptr(), 0, score.data_ptr(), mode, False) for w in ws]
+                fns = [lambda w=w: plan.run([w], (), score, mode, False) for w in ws]
                 report(nm + f" ({plan.n_items} items)", timed(fns, args.iters), plan.algorithmic_bytes(mode))
         if want("taylor"):
-            fns = [lambda w=w, g=g: plan.run(w.data_ptr(), g.data_ptr(), score.data_ptr(), nat.IMP_TAYLOR, True)
+            fns = [lambda w=w, g=g: plan.run([w], [g], score, nat.IMP_TAYLOR, True)
                    for w, g in zip(ws, gs)]
             report("importance_taylor", timed(fns, args.iters), plan.algorithmic_bytes(nat.IMP_TAYLOR))
         if want("gather"):
@@ -100,7 +100,7 @@ def main():
                 gplan = ops.GatherPlan(specs, dev)
                 idx_t = torch.from_numpy(np.concatenate(idx)).to(dev)
                 dsts = [torch.empty(dpos, device=dev) for _ in range(copies)]
-                fns = [lambda w=w, d=d: gplan.run(w.data_ptr(), d.data_ptr(), idx_t.data_ptr()) for w, d in zip(ws, dsts)]
+                fns = [lambda w=w, d=d: gplan.run([w], d, idx_t) for w, d in zip(ws, dsts)]
                 report(f"{label} ({gplan.n_items} items)", timed(fns, args.iters), gplan.algorithmic_bytes())
                 del dsts
             # both lists, as in a whole-model pruning step: every second out-channel AND in-channel
@@ -115,7 +115,7 @@ def main():
             gplan = ops.GatherPlan(specs, dev)
             idx_t = torch.from_numpy(np.concatenate(idx)).to(dev)
             dsts = [torch.empty(dpos, device=dev) for _ in range(copies)]
-            fns = [lambda w=w, d=d: gplan.run(w.data_ptr(), d.data_ptr(), idx_t.data_ptr()) for w, d in zip(ws, dsts)]
+            fns = [lambda w=w, d=d: gplan.run([w], d, idx_t) for w, d in zip(ws, dsts)]
             report(f"gather_out50_in50 ({gplan.n_items} items)", timed(fns, args.iters), gplan.algorithmic_bytes())
             del dsts
         del ws, gs

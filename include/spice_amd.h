@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPICE_ABI_VERSION 2
+#define SPICE_ABI_VERSION 3
 
 #define SPICE_OK 0
 #define SPICE_ERR_ARG 10001         /* null pointer, negative size, misaligned base */
@@ -259,8 +259,11 @@ typedef struct spice_gather_item {
 int64_t spice_gather_plan(const spice_gather_desc *tensors, int32_t n_tensors,
                           spice_gather_item *items, int64_t capacity);
 
+/* plan_flags: bitwise OR of the `flags` of the planned items (the caller has them on the host);
+ * staged items (bit2) are only honoured when it says so, otherwise they take the element path. */
 int spice_gather_run(const float *src_base, float *dst_base, const int64_t *idx_base,
-                     const spice_gather_item *d_items, int64_t n_items, void *stream);
+                     const spice_gather_item *d_items, int64_t n_items, int32_t plan_flags,
+                     void *stream);
 
 /* ------------------------------------------------------------------------- *
  * (5) Bilinear up-sampling of NCHW planes (the models' decoder and head).

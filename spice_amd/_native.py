@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libspice_amd.so")
 TORCH_LIB_PATH = os.path.join(_HERE, "lib", "libspice_torch.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 ERR_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_BLAS, ERR_STATIC_LIMIT = 10001, 10002, 10003, 10004, 10005
 IMP_L1, IMP_L2, IMP_TAYLOR = 0, 1, 2
 
@@ -89,7 +89,7 @@ SIGNATURES = {
     "spice_argmax_confusion_update": (c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_int64,
                                                 c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "spice_gather_plan": (c_int64, [POINTER(GatherDesc), c_int32, POINTER(GatherItem), c_int64]),
-    "spice_gather_run": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "spice_gather_run": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "spice_bn_act": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                c_int64, c_int64, c_int64, c_int32, c_void_p]),
     "spice_depthwise_conv3x3": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int64, c_int32, c_int32,

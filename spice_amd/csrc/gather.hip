@@ -25,7 +25,7 @@ static int64_t gather_target_elems() {
 constexpr int kGatherStageWords = 5120;   // 20 KB of source rows per workgroup
 constexpr int kGatherStageCols = 2048;    // 8 KB table of kept-column offsets
 constexpr size_t kGatherLdsBytes = (size_t)(kGatherStageWords + kGatherStageCols) * 4;
-constexpr int64_t kGatherStageTargetElems = 2048;  // destination words per staged item
+constexpr int64_t kGatherStageTargetElems = 4096;  // destination words per staged item
 
 static int64_t gather_stage_target_elems() {
     const char *e = getenv("SPICE_GATHER_STAGE_TARGET_ELEMS");  // tuning knob (host side only)
@@ -33,9 +33,18 @@ static int64_t gather_stage_target_elems() {
     return (v >= 256 && v <= (1 << 22)) ? v : kGatherStageTargetElems;
 }
 
+static bool gather_stage_enabled() {
+    const char *e = getenv("SPICE_GATHER_STAGE");  // tuning knob (host side only): 0 = never stage rows in LDS
+    return !(e && atoi(e) == 0);
+}
+
 // One staged work item (flags bit2): rows and kept columns as described above.  Requirements, all
 // checked by the planner: 16-byte aligned source rows and destination rows, row_len % 4 == 0,
-// n_rows * src_cols * inner <= kGatherStageWords, dst_cols <= kGatherStageCols.
+// src_cols * inner <= kGatherStageWords, dst_cols <= kGatherStageCols.  The item's rows go through
+// LDS in batches of as many rows as fit; the next batch's source rows are already on their way
+// (held in registers, five 16-byte loads per lane) while the current one is picked apart.
+constexpr int kGatherStageRegs = kGatherStageWords / 4 / kGatherThreads;  // 16-byte registers per lane per batch
+
 __device__ __forceinline__ void gather_staged(const spice_gather_item &it, const unsigned *__restrict__ src,
                                               unsigned *__restrict__ dst, const long long *__restrict__ idx_out,
                                               const long long *__restrict__ idx_in, unsigned *lds) {
@@ -46,53 +55,61 @@ __device__ __forceinline__ void gather_staged(const spice_gather_item &it, const
     unsigned *rows = lds;
     int *coltab = reinterpret_cast<int *>(lds + kGatherStageWords);
     for (int i = tid; i < it.dst_cols; i += kGatherThreads) coltab[i] = (int)idx_in[i] * inner;
-    // source rows -> LDS, flat over (row, 16-byte chunk)
     const int stride4 = src_stride >> 2;
-    const int total4 = it.n_rows * stride4;
+    const int rows_b = min(it.n_rows, kGatherStageWords / src_stride);  // rows per batch (>= 1)
     const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
     uint4 *rows4 = reinterpret_cast<uint4 *>(rows);
-    int f0 = tid;
-    for (; f0 + 3 * kGatherThreads < total4; f0 += 4 * kGatherThreads) {
-        long long so[4];
-        int col[4];
+    uint4 *dst4 = reinterpret_cast<uint4 *>(dst);
+
+    uint4 regs[kGatherStageRegs];
+    auto load_batch = [&](int r0) {  // source rows r0 .. r0+nr-1 -> registers, flat over (row, 16-byte chunk)
+        const int nr = min(rows_b, it.n_rows - r0);
+        const int total4 = nr * stride4;
+        long long so[kGatherStageRegs];
+        int col[kGatherStageRegs];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int f = f0 + u * kGatherThreads;
+        for (int u = 0; u < kGatherStageRegs; ++u) {
+            const int f = min(tid + u * kGatherThreads, total4 - 1);  // surplus lanes repeat the last chunk
             const int row = f / stride4;
             col[u] = f - row * stride4;
-            so[u] = idx_out ? idx_out[row] : (long long)(it.row0 + row);
+            so[u] = idx_out ? idx_out[r0 + row] : (long long)(it.row0 + r0 + row);
         }
-        uint4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = ld_stream16(src4 + (so[u] * stride4 + col[u]));
+        for (int u = 0; u < kGatherStageRegs; ++u) regs[u] = ld_stream16(src4 + (so[u] * stride4 + col[u]));
+    };
+
+    load_batch(0);
+    for (int r0 = 0; r0 < it.n_rows; r0 += rows_b) {
+        const int nr = min(rows_b, it.n_rows - r0);
+        const int total4 = nr * stride4;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) rows4[f0 + u * kGatherThreads] = v[u];
-    }
-    for (; f0 < total4; f0 += kGatherThreads) {
-        const int row = f0 / stride4;
-        const long long so = idx_out ? idx_out[row] : (long long)(it.row0 + row);
-        rows4[f0] = ld_stream16(src4 + (so * stride4 + (f0 - row * stride4)));
-    }
-    __syncthreads();
-    // kept columns out of LDS, four consecutive destination words per lane (never across a row)
-    const int total = it.n_rows * row_len;
-    uint4 *dst4 = reinterpret_cast<uint4 *>(dst);
-    for (int e0 = tid * 4; e0 < total; e0 += 4 * kGatherThreads) {
-        const int row = e0 / row_len;
-        const int rem = e0 - row * row_len;
-        int i = inner == 1 ? rem : rem / inner;
-        int k = rem - i * inner;
-        const unsigned *r = rows + row * src_stride;
-        unsigned v[4];
+        for (int u = 0; u < kGatherStageRegs; ++u) {
+            const int f = tid + u * kGatherThreads;
+            if (f < total4) rows4[f] = regs[u];
+        }
+        __syncthreads();
+        if (r0 + rows_b < it.n_rows) load_batch(r0 + rows_b);
+        // kept columns out of LDS, four consecutive destination words per lane (never across a row)
+        const int total = nr * row_len;
+        uint4 *out4 = dst4 + (((int64_t)r0 * row_len) >> 2);
+        for (int e0 = tid * 4; e0 < total; e0 += 4 * kGatherThreads) {
+            const int row = e0 / row_len;
+            const int rem = e0 - row * row_len;
+            int i = inner == 1 ? rem : rem / inner;
+            int k = rem - i * inner;
+            const unsigned *r = rows + row * src_stride;
+            unsigned v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            v[u] = r[coltab[i] + k];
-            if (++k == inner) {
-                k = 0;
-                ++i;
+            for (int u = 0; u < 4; ++u) {
+                v[u] = r[coltab[i] + k];
+                if (++k == inner) {
+                    k = 0;
+                    ++i;
+                }
             }
+            st_stream16(out4 + (e0 >> 2), make_uint4(v[0], v[1], v[2], v[3]));
         }
-        st_stream16(dst4 + (e0 >> 2), make_uint4(v[0], v[1], v[2], v[3]));
+        __syncthreads();
     }
 }
 
@@ -118,12 +135,30 @@ __device__ __forceinline__ void gather_words(const spice_gather_item &it, const 
         i = inner == 1 ? rem : rem / inner;
         k = rem - i * inner;
     };
+    // N words = N/4 quads of four consecutive destination words; one division pair per quad, the
+    // other three positions follow by counting (inner index, then column, then row)
     auto fetch_n = [&](int e0, int stride, unsigned *v, auto n_tag) {
         constexpr int N = decltype(n_tag)::value;
         int row[N], i[N], k[N];
         long long so[N], ci[N];
 #pragma unroll
-        for (int u = 0; u < N; ++u) locate(e0 + (u >> 2) * stride + (u & 3), row[u], i[u], k[u]);
+        for (int q = 0; q < N / 4; ++q) {
+            int r, ii, kk;
+            locate(e0 + q * stride, r, ii, kk);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                row[4 * q + u] = r;
+                i[4 * q + u] = ii;
+                k[4 * q + u] = kk;
+                if (++kk == inner) {
+                    kk = 0;
+                    if (++ii == it.dst_cols) {
+                        ii = 0;
+                        ++r;
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < N; ++u) {
             so[u] = HAS_OUT ? idx_out[row[u]] : (long long)(it.row0 + row[u]);
@@ -168,7 +203,7 @@ __device__ __forceinline__ void gather_words(const spice_gather_item &it, const 
 __global__ __launch_bounds__(kGatherThreads) void gather_kernel(
     const unsigned *__restrict__ src_base, unsigned *__restrict__ dst_base,
     const long long *__restrict__ idx_base, const spice_gather_item *__restrict__ items,
-    int bases_vec_ok) {
+    int bases_vec_ok, int have_lds) {
     extern __shared__ unsigned gather_lds[];
     const spice_gather_item it = items[blockIdx.x];
     const int tid = threadIdx.x;
@@ -217,7 +252,7 @@ __global__ __launch_bounds__(kGatherThreads) void gather_kernel(
         }
         return;
     }
-    if (idx_in != nullptr && bases_vec_ok && (it.flags & 4)) {
+    if (idx_in != nullptr && bases_vec_ok && have_lds && (it.flags & 4)) {
         gather_staged(it, src, dst, idx_out, idx_in, gather_lds);
         return;
     }
@@ -258,13 +293,12 @@ extern "C" int64_t spice_gather_plan(const spice_gather_desc *tensors, int32_t n
         // rows per item: the kernel walks an item's destination as one contiguous range, so any
         // row count will do; small items keep many workgroups in flight
         // staged path: in-channel list, 16-byte aligned source and destination rows, rows that fit LDS
-        const bool stage = d.idx_in_off >= 0 && (row_len % 4 == 0) && (src_stride % 4 == 0) && (d.src_off % 4 == 0) &&
+        const bool stage = gather_stage_enabled() && d.idx_in_off >= 0 && (row_len % 4 == 0) && (src_stride % 4 == 0) && (d.src_off % 4 == 0) &&
                            (d.dst_off % 4 == 0) && src_stride <= kGatherStageWords && d.dst_cols <= kGatherStageCols;
         int64_t rpi = (stage ? gather_stage_target_elems() : target) / row_len;
-        if (stage && rpi > kGatherStageWords / src_stride) rpi = kGatherStageWords / src_stride;
         if (rpi < 1) rpi = 1;
         const int64_t n_it = ceil_div(d.dst_rows, rpi);
-        rpi = ceil_div(d.dst_rows, n_it);  // never larger than before: the LDS bound still holds
+        rpi = ceil_div(d.dst_rows, n_it);
         for (int64_t r0 = 0; r0 < d.dst_rows; r0 += rpi, ++n) {
             if (items == nullptr || n >= capacity) continue;
             spice_gather_item &it = items[n];
@@ -286,17 +320,20 @@ extern "C" int64_t spice_gather_plan(const spice_gather_desc *tensors, int32_t n
 }
 
 extern "C" int spice_gather_run(const float *src_base, float *dst_base, const int64_t *idx_base,
-                                const spice_gather_item *d_items, int64_t n_items, void *stream) {
+                                const spice_gather_item *d_items, int64_t n_items, int32_t plan_flags,
+                                void *stream) {
     if (n_items < 0 || n_items > INT32_MAX) return SPICE_ERR_ARG;
     if (n_items == 0) return SPICE_OK;
     if (!src_base || !dst_base || !d_items) return SPICE_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(src_base) & 3u) || (reinterpret_cast<uintptr_t>(dst_base) & 3u))
         return SPICE_ERR_ARG;
     const int vec_ok = aligned16(src_base) && aligned16(dst_base);
-    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)n_items), dim3(kGatherThreads), kGatherLdsBytes,
+    // LDS only when the plan holds staged items: the allocation limits the workgroups per CU
+    const size_t lds = (plan_flags & 4) ? kGatherLdsBytes : 0;
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)n_items), dim3(kGatherThreads), lds,
                        static_cast<hipStream_t>(stream), reinterpret_cast<const unsigned *>(src_base),
                        reinterpret_cast<unsigned *>(dst_base),
-                       reinterpret_cast<const long long *>(idx_base), d_items, vec_ok);
+                       reinterpret_cast<const long long *>(idx_base), d_items, vec_ok, lds ? 1 : 0);
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;
 }

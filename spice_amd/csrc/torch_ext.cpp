@@ -107,7 +107,8 @@ void importance_cols_run(std::vector<Tensor> weights, Tensor scores, Tensor part
 
 // ---- (4) gather -----------------------------------------------------------------------------
 
-void gather_run(std::vector<Tensor> srcs, Tensor dst, const Tensor &idx, const Tensor &items, int64_t n_items) {
+void gather_run(std::vector<Tensor> srcs, Tensor dst, const Tensor &idx, const Tensor &items, int64_t n_items,
+                int64_t plan_flags) {
     check_dev(dst, "dst", at::kFloat);
     check_dev(idx, "idx", at::kLong);
     check_same_device(dst, idx, "idx");
@@ -116,7 +117,7 @@ void gather_run(std::vector<Tensor> srcs, Tensor dst, const Tensor &idx, const T
     c10::DeviceGuard guard(dst.device());
     check_rc(spice_gather_run(src_base, dst.data_ptr<float>(), idx.data_ptr<int64_t>(),
                               reinterpret_cast<const spice_gather_item *>(items.data_ptr()), n_items,
-                              current_stream(dst)),
+                              (int32_t)plan_flags, current_stream(dst)),
              "spice_gather_run");
 }
 
@@ -363,7 +364,8 @@ TORCH_LIBRARY(spice, m) {
           "bool accumulate) -> ()", &importance_run);
     m.def("importance_cols_run(Tensor[] weights, Tensor(a!) scores, Tensor(b!) partial, Tensor items, int n_items, "
           "Tensor folds, int n_folds, int mode) -> ()", &importance_cols_run);
-    m.def("gather_run(Tensor[] srcs, Tensor(a!) dst, Tensor idx, Tensor items, int n_items) -> ()", &gather_run);
+    m.def("gather_run(Tensor[] srcs, Tensor(a!) dst, Tensor idx, Tensor items, int n_items, int plan_flags) -> ()",
+          &gather_run);
     m.def("confusion_update(Tensor(a!) conf, Tensor preds, Tensor target, int num_classes, Tensor(b!) workspace) -> ()",
           &confusion_update);
     m.def("confusion_update_static(Tensor(a!) conf, Tensor preds, Tensor target, int num_classes, "

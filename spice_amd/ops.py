@@ -335,6 +335,9 @@ class GatherPlan:
         got = L.spice_gather_plan(descs, nt, items, n)
         assert got == n
         self.n_items = int(n)
+        self.plan_flags = 0
+        for k in range(self.n_items):
+            self.plan_flags |= items[k].flags
         self.items = _upload_items(items, self.n_items, self.device)
         self.moved_elems = sum(s.dst_rows * s.dst_cols * s.inner for s in self.specs)
         self.index_elems = sum((s.dst_rows if s.idx_out_off >= 0 else 0) +
@@ -343,7 +346,7 @@ class GatherPlan:
     def run(self, srcs: Sequence[torch.Tensor], dst: torch.Tensor, idx: torch.Tensor) -> None:
         """One launch for every planned tensor.  The plan's source offsets count from the lowest
         address among `srcs`, destination offsets from `dst`, index offsets from `idx`."""
-        spice_ops().gather_run(list(srcs), dst, idx, self.items, self.n_items)
+        spice_ops().gather_run(list(srcs), dst, idx, self.items, self.n_items, self.plan_flags)
 
     def algorithmic_bytes(self) -> int:
         return 8 * self.moved_elems + 8 * self.index_elems

@@ -20,7 +20,9 @@ class _KDLiteFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, student, teacher, labels, opts):
-        want = student.requires_grad and torch.is_grad_enabled()
+        # autograd runs forward() with grad mode off, so torch.is_grad_enabled() says nothing here;
+        # needs_input_grad is what tells whether a backward through the student will come
+        want = bool(ctx.needs_input_grad[0])
         ctx.set_materialize_grads(False)
         out3, grad, _ = ops.kdlite_forward(student.detach(), teacher.detach(), labels, want_grad=want, **opts)
         ctx.opts = opts
@@ -40,7 +42,7 @@ class _KDLiteFunction(torch.autograd.Function):
             if g_total is None:
                 return None, None, None, None
             grad = ctx.saved_grad
-            if grad is None:  # forward ran without grad mode knowledge: recompute
+            if grad is None:  # a second backward through the same graph: the first one consumed the buffer
                 _, grad, _ = ops.kdlite_forward(student.detach(), teacher.detach(), labels,
                                                 want_grad=True, **ctx.opts)
             ops.scale_inplace(grad, g_total.reshape(1).float().contiguous())

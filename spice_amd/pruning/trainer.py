@@ -69,14 +69,18 @@ class PruningTrainer:
 
     def _create_kd_subset_loader(self, train_loader: DataLoader) -> DataLoader:
         """A seeded sample of int(len * kd_data_ratio) training items, reshuffled every epoch
-        (pruning/trainer.py:69-94).  Under several ranks every rank draws the same sample and
-        keeps its stride of it."""
+        (pruning/trainer.py:69-94).  Under several ranks every rank draws the same sample, the list is
+        padded with its own first items to a multiple of the world size (as DistributedSampler pads),
+        and each rank keeps its stride of it: every rank then sees the same number of samples and of
+        batches, so the gradient all-reduces of the ranks pair up."""
         data = train_loader.dataset
         n = len(data)
         keep = int(n * self.config.kd_data_ratio)
         picked = random.Random(self.config.seed).sample(range(n), keep)
         rank, world = sdist.world()
-        if world > 1:
+        if world > 1 and picked:
+            short = (-len(picked)) % world
+            picked = picked + (picked * world)[:short]
             picked = picked[rank::world]
         g = torch.Generator()
         g.manual_seed(self.config.seed)

@@ -89,6 +89,40 @@ def test_loss_components_differentiate_separately(dev):
     assert not out_ng["total"].requires_grad
 
 
+def test_training_step_launches_the_fused_loss_once(dev, monkeypatch):
+    """Forward + backward of a training step is ONE spice_kdlite_forward call that writes the gradient
+    too (pruning/trainer.py:179-182); an evaluation forward asks for no gradient; a backward through
+    ce or kd alone recomputes with the actual upstream gradients."""
+    from spice_amd import ops
+    calls = []
+    real = ops.kdlite_forward
+
+    def counting(*a, **k):
+        calls.append(bool(k.get("want_grad", False)))
+        return real(*a, **k)
+
+    monkeypatch.setattr(ops, "kdlite_forward", counting)
+    name = "c21_default"
+    t = torch.from_numpy(KD[f"{name}/teacher"]).to(dev)
+    lab = torch.from_numpy(KD[f"{name}/labels"]).to(dev)
+    loss = KDLiteLoss(temperature=4.0, alpha=0.7, num_classes=21).to(dev)
+    s = torch.from_numpy(KD[f"{name}/student"]).to(dev).requires_grad_(True)
+    out = loss(s, t, lab)
+    out["total"].backward()
+    assert calls == [True]
+    g_ref = KD[f"{name}/grad"]
+    assert np.abs(s.grad.cpu().numpy() - g_ref).max() <= 1e-5 * np.abs(g_ref).max()
+    calls.clear()
+    with torch.no_grad():
+        loss(s, t, lab)
+    loss(s.detach(), t, lab)
+    assert calls == [False, False]
+    calls.clear()
+    out = loss(s, t, lab)
+    torch.autograd.grad(out["kd"], s)
+    assert calls == [True, True]
+
+
 def test_loss_rejects_cpu_tensors():
     loss = KDLiteLoss(num_classes=21)
     x = torch.zeros(1, 21, 4, 4)

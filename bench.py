@@ -13,6 +13,13 @@ evaluates K candidates of its cost-balanced share; the per-candidate tables are 
 all-reduce inside the timed region.  Set-up outside the timed region: model build, the Taylor
 calibration pass (HIP Taylor reduction) with quota allocation, group magnitude importance (HIP),
 launch plans.  Rank 0 prints ONE JSON line.
+
+    python bench.py --gpus N --strong
+times the WHOLE sweep instead (strong scaling: the 414 candidates are fixed, ranks share them):
+SensitivitySweep.run() wall-clock per rank, including the geometry pass, the cost model and the
+cost-balanced partition, launch plans, solver lookups for the rank's new convolution shapes, the
+teacher forward, every candidate and the all-reduce of the tables.  The find-database warm-up,
+the model build and the sharded Taylor calibration are reported beside it under "setup".
 """
 from __future__ import annotations
 
@@ -43,7 +50,7 @@ def build_inputs(dev):
     return torch.from_numpy(img).to(dev), torch.from_numpy(lab).to(dev)
 
 
-def taylor_and_quotas(model, images, labels, dev):
+def taylor_and_quotas(model, images, labels, dev, shard=False):
     """The sensitivity analysis of the magnitude_taylor strategy: Taylor scores over calibration
     batches (labels must be in [0,C): ignore pixels are mapped to class 0) and layer quotas."""
     from spice_amd.pruning.pruner import LayerQuotaCalculator
@@ -53,7 +60,7 @@ def taylor_and_quotas(model, images, labels, dev):
     half = BATCH // 2
     loader = [(images[:half], cal[:half]), (images[half:], cal[half:])]
     t0 = time.perf_counter()
-    scores = compute_taylor_scores(model, loader, str(dev), max_batches=2)
+    scores = compute_taylor_scores(model, loader, str(dev), max_batches=2, shard=shard)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
 
@@ -83,15 +90,16 @@ def event_ms(fn, iters, warmup=3, batch=8):
 
 
 def pmc_traffic(kernel_key):
-    """HBM bytes per launch from the newest committed rocprofv3 --pmc summary (None if absent)."""
+    """(HBM bytes per launch, file it was read from): the figure comes from the newest committed
+    rocprofv3 --pmc summary under profiles/, not from this run (counters need a run of their own)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")), reverse=True):
         try:
             with open(path) as f:
-                return json.load(f)["kernels"][kernel_key]["hbm_bytes_corrected"]
+                return json.load(f)["kernels"][kernel_key]["hbm_bytes_corrected"], os.path.relpath(path, ROOT)
         except (OSError, KeyError, ValueError):
             continue
-    return None
+    return None, None
 
 
 def kernel_table(dev):
@@ -227,11 +235,63 @@ def cpu_candidate_baseline(model, sweep, images, labels):
                       f"confusion, KD-Lite loss; {dt:.2f} s; selected channels equal to the HIP path: {same}"}
 
 
+def strong_mode(args, sweep, images, labels, dev, rank, world, tune_s, taylor_s, build_s):
+    """The whole sweep, wall-clock, max over ranks; rank 0 prints the JSON line."""
+    n_cand = len(sweep.candidates)
+    sdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = sweep.run(images, labels)
+    torch.cuda.synchronize()
+    mine_s = time.perf_counter() - t0
+    sdist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    sdist.all_reduce_max_(t)
+    elapsed = float(t.item())
+    # per-rank split: own work (set-up of the share + candidates) against waiting for the slowest rank
+    share = torch.zeros(world, 4, device=dev, dtype=torch.float64)
+    share[rank] = torch.tensor([sweep.last_share["candidates"], sweep.last_share["cost"],
+                                sweep.last_share["busy_s"], mine_s], dtype=torch.float64)
+    sdist.all_reduce_sum_(share)
+    share = share.cpu().numpy()
+    miou = res["miou"].cpu().numpy()
+    result = {
+        "metric": "sensitivity-sweep candidates/sec",
+        "value": round(n_cand / elapsed, 3), "unit": "candidates/s",
+        "n_gpus": world, "steps": n_cand, "warmup": 0,
+        "ms_per_step": round(1e3 * elapsed / n_cand, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "DeepLabV3Plus_resnet magnitude_taylor sensitivity sweep, ALL candidates: geometry pass + cost "
+                               "model + partition + launch plans + solver lookups + teacher forward + every candidate "
+                               "(gather, forward, arg-max/confusion, KD-Lite loss) + all-reduce of the tables",
+                   "num_classes": CLASSES, "eval_batch": [BATCH, 3, SIZE, SIZE], "candidates": n_cand,
+                   "groups": len(sweep.groups), "ratios": list(DEFAULT_RATIOS),
+                   "parallelism": f"candidates sharded over {world} rank(s) by estimated cost (LPT)"},
+        "sweep_s": round(elapsed, 4),
+        "ranks": [{"rank": r, "candidates": int(share[r, 0]), "cost_share": round(float(share[r, 1] / max(share[:, 1].sum(), 1e-9)), 4),
+                   "busy_s": round(float(share[r, 2]), 4), "run_s": round(float(share[r, 3]), 4),
+                   "idle_s": round(float(elapsed - share[r, 3]), 4)} for r in range(world)],
+        "setup": {"miopen_find_db_warmup_s": round(tune_s, 1), "model_build_s": round(build_s, 3),
+                  "taylor_calibration_s": round(taylor_s, 3), "taylor_batches": 2, "taylor_sharded": world > 1,
+                  "new_conv_problems_seen": len(sweep._warmed)},
+        "check": {"miou_min": round(float(miou.min()), 6), "miou_max": round(float(miou.max()), 6),
+                  "confusion_sum_per_candidate": int(res["confusion"][0].sum().item())},
+    }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: time the whole sweep (all candidates shared by the ranks) instead of K per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--fp32-forward", action="store_true", help="forward without fp16 autocast")
@@ -270,14 +330,20 @@ def main():
     torch.backends.cudnn.benchmark = False
 
     torch.manual_seed(1234)
+    t_build = time.perf_counter()
     model = nets.create_model("DeepLabV3Plus", "resnet50", CLASSES).to(dev).eval()
     images, labels = build_inputs(dev)
-    scores, quotas, taylor_s = taylor_and_quotas(model, images, labels, dev)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t_build
+    scores, quotas, taylor_s = taylor_and_quotas(model, images, labels, dev, shard=args.strong)
     ignored = [m for m in model.segmentation_head.modules() if isinstance(m, torch.nn.Conv2d)]
     sweep = SensitivitySweep(model, CLASSES, DEFAULT_RATIOS, ignored_layers=ignored,
                              autocast_dtype=None if args.fp32_forward else torch.float16)
     n_cand = len(sweep.candidates)
-    parts = sdist.partition_by_cost([c.cost for c in sweep.candidates], world)
+    if args.strong:
+        strong_mode(args, sweep, images, labels, dev, rank, world, tune_s, taylor_s, build_s)
+        return
+    parts = sdist.partition_by_cost(sweep.candidate_costs(images), world)
     mine = parts[rank]
     total_steps = args.warmup + args.steps
     todo = [mine[i % len(mine)] for i in range(total_steps)]
@@ -342,7 +408,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "spice::kdlite_main_kernel<4,false,false,false> (one launch per "
                      "spice_kdlite_forward call)", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS,
                      "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4),
-                     "traffic": pmc_traffic("spice::kdlite_main_kernel<4, false, false, false>"),
+                     "traffic": pmc_traffic("spice::kdlite_main_kernel<4, false, false, false>")[0],
+                     "traffic_source": pmc_traffic("spice::kdlite_main_kernel<4, false, false, false>")[1],
                      "algorithmic_bytes_per_launch": kd_bytes, "avg_launch_us": round(1e3 * kd_ms, 2),
                      "launches_timed": len(kd_events)},
         "setup": {"miopen_find_db_warmup_s": round(tune_s, 1), "timed_prepare_s": round(prep_s, 4), "warm_mode": args.warm_mode,

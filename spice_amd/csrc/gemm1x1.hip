@@ -34,8 +34,17 @@ struct GemmPlan {
     hipblasLtMatmulDesc_t desc = nullptr;
     hipblasLtMatrixLayout_t lx = nullptr, lw = nullptr, ly = nullptr;
     hipblasLtMatmulAlgo_t algo;
-    int status = SPICE_OK;   // a problem hipBLASLt has no algorithm for stays refused
+    int status = SPICE_OK;   // SPICE_ERR_UNSUPPORTED: hipBLASLt has no scratch-free algorithm for this size (kept: it will not change)
 };
+
+static void destroy_plan(GemmPlan &p) {
+    if (p.desc) hipblasLtMatmulDescDestroy(p.desc);
+    if (p.lx) hipblasLtMatrixLayoutDestroy(p.lx);
+    if (p.lw) hipblasLtMatrixLayoutDestroy(p.lw);
+    if (p.ly) hipblasLtMatrixLayoutDestroy(p.ly);
+    p.desc = nullptr;
+    p.lx = p.lw = p.ly = nullptr;
+}
 
 struct GemmDevice {
     hipblasLtHandle_t handle = nullptr;
@@ -98,6 +107,9 @@ extern "C" int spice_conv1x1_f16(const void *x, const void *weight, void *y, int
         if (it == d.plans.end()) {
             GemmPlan fresh;
             fresh.status = build_plan(d, key, fresh);
+            if (fresh.status != SPICE_OK) destroy_plan(fresh);   // nothing of a failed plan is kept alive
+            // a library error may be transient: only a finished plan or a definite "no algorithm" is remembered
+            if (fresh.status != SPICE_OK && fresh.status != SPICE_ERR_UNSUPPORTED) return fresh.status;
             it = d.plans.emplace(key, fresh).first;
         }
         plan = it->second;

@@ -26,6 +26,9 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
         if backend == "nccl" or backend is None:
             raise RuntimeError(f"LOCAL_RANK={local} but only {n_dev} GPU(s) visible (RCCL needs one GPU per rank)")
         local %= n_dev
+    if n_dev > 0:
+        # whatever the backend: launches address the current device's handles and per-device state
+        torch.cuda.set_device(local)
     if world > 1:
         # one MIOpen user database per rank: ranks of one node would otherwise serialise on its file lock
         os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(

@@ -197,7 +197,8 @@ class ModelManager:
         self.model_factory = ModelFactory()
         self.pruning_dir = self._create_output_directory()
         self.intermediate_dir = self.pruning_dir / "intermediate"
-        self.intermediate_dir.mkdir(parents=True, exist_ok=True)
+        if sdist.world()[0] == 0:
+            self.intermediate_dir.mkdir(parents=True, exist_ok=True)
 
     def _create_output_directory(self) -> Path:
         c = self.config
@@ -206,8 +207,17 @@ class ModelManager:
             name += "_kd_refine" if getattr(c, "kd_mode", "") == "refine" else "_kd"
         if c.use_timestamp:
             name = datetime.datetime.now().strftime("%Y%m%d_%H%M%S") + "_" + name
+        rank, world = sdist.world()
+        if world > 1:   # one run directory for all ranks: rank 0 names it (its clock), the others follow
+            import torch.distributed as tdist
+            box = [name]
+            tdist.broadcast_object_list(box, src=0)
+            name = box[0]
         d = Path(c.output_dir) / name
-        d.mkdir(parents=True, exist_ok=True)
+        if rank == 0:
+            d.mkdir(parents=True, exist_ok=True)
+        if world > 1:
+            sdist.barrier()
         return d
 
     def load_model(self) -> nn.Module:
@@ -301,7 +311,8 @@ class StructuredPruner:
                 raise RuntimeError(f"device '{self.config.device}': this implementation runs on HIP devices only")
             model, teacher_model, initial_info = self._initialize_models()
             pruner, additional_info = self._setup_pruning(model)
-            self.orchestrator.save_reports(self.model_manager.pruning_dir, additional_info)
+            if sdist.world()[0] == 0:   # one writer per run
+                self.orchestrator.save_reports(self.model_manager.pruning_dir, additional_info)
             model = self._execute_progressive_pruning(model, pruner, teacher_model)
             model = self.step_executor.execute_final_training(model, self.trainer, teacher_model)
             return self._finalize_pruning(model, initial_info)

@@ -41,7 +41,7 @@ class Candidate:
     group: int          # index into SensitivitySweep.groups
     ratio: float
     pruned: np.ndarray  # channel ids removed from the group, ascending
-    cost: float         # relative cost estimate (for balancing ranks)
+    cost: float         # relative cost estimate (for balancing ranks): see SensitivitySweep.candidate_costs
 
 
 class SensitivitySweep:
@@ -71,11 +71,88 @@ class SensitivitySweep:
                     continue
                 seen.add(n)
                 self.candidates.append(Candidate(len(self.candidates), gi, float(r), np.sort(order[:n]),
-                                                 1.0 - 0.5 * r * g.size / max(g.size, 1)))
+                                                 self._weight_share_cost(g, n)))
         self.jobs: Dict[int, SliceJob] = {}
         # when set to a list, evaluate() appends a (start, end) HIP event pair around each KD-Lite launch
         self.kd_events: Optional[list] = None
         self._geometry, self._geometry_for, self._warmed = {}, None, set()
+
+    # -- cost of a candidate, for balancing ranks ---------------------------------------------
+    #: share of a candidate's time that does not shrink with the network (host work per launch,
+    #: the loss and histogram kernels on the full-size logits); measured on MI355X: about half
+    FIXED_COST_SHARE = 0.5
+
+    def _sliced_conv_dims(self, g, n: int) -> Dict[nn.Module, tuple]:
+        """(in_channels, out_channels, groups) of every convolution coupled to group `g` once `n`
+        of its channels are gone."""
+        dims: Dict[nn.Module, list] = {}
+        for m in g.members:
+            mod = m.module
+            if not isinstance(mod, nn.Conv2d):
+                continue
+            d = dims.setdefault(mod, [mod.in_channels, mod.out_channels, mod.groups])
+            if m.kind == "out":
+                d[1] -= n
+            elif m.kind == "in":
+                d[0] -= n
+            elif m.kind == "dw":
+                d[0] -= n
+                d[1] -= n
+                d[2] -= n
+        return {k: tuple(v) for k, v in dims.items()}
+
+    def _weight_share_cost(self, g, n: int) -> float:
+        """Before any geometry is known: the convolutions' multiply-accumulates per output POSITION
+        (= weight elements) that remain, as a share of the un-pruned network's."""
+        if not hasattr(self, "_weights_total"):
+            self._weights_total = float(sum(m.weight.numel() for m in self.model.modules() if isinstance(m, nn.Conv2d)))
+        gone = 0.0
+        for mod, (cin, cout, groups) in self._sliced_conv_dims(g, n).items():
+            k = mod.kernel_size[0] * mod.kernel_size[1]
+            gone += mod.weight.numel() - cout * (cin // max(groups, 1)) * k
+        return self.FIXED_COST_SHARE + (1.0 - self.FIXED_COST_SHARE) * (1.0 - gone / max(self._weights_total, 1.0))
+
+    def candidate_costs(self, images: torch.Tensor) -> List[float]:
+        """Cost of every candidate = FIXED_COST_SHARE + (1 - FIXED_COST_SHARE) * (multiply-accumulates
+        of the SLICED network's convolutions on `images`) / (those of the un-pruned network), the
+        model tp.utils.count_ops_and_params applies to convolutions (pruning/pruning_core.py:192):
+        out positions x out channels x in channels / groups x kernel area.  Also stored on the
+        candidates.  Needs one forward of the un-pruned network (to learn every layer's geometry)."""
+        self._ensure_geometry(images)
+        macs: Dict[nn.Module, float] = {}
+        for mod, ((n, _, h, w), _) in self._geometry.items():
+            ho = (h + 2 * mod.padding[0] - mod.dilation[0] * (mod.kernel_size[0] - 1) - 1) // mod.stride[0] + 1
+            wo = (w + 2 * mod.padding[1] - mod.dilation[1] * (mod.kernel_size[1] - 1) - 1) // mod.stride[1] + 1
+            macs[mod] = float(n * ho * wo)   # output positions; times weight elements below
+        total = sum(p * mod.weight.numel() for mod, p in macs.items())
+        out = []
+        for cand in self.candidates:
+            g = self.groups[cand.group]
+            gone = 0.0
+            for mod, (cin, cout, groups) in self._sliced_conv_dims(g, len(cand.pruned)).items():
+                if mod in macs:
+                    k = mod.kernel_size[0] * mod.kernel_size[1]
+                    gone += macs[mod] * (mod.weight.numel() - cout * (cin // max(groups, 1)) * k)
+            cand.cost = self.FIXED_COST_SHARE + (1.0 - self.FIXED_COST_SHARE) * (1.0 - gone / max(total, 1.0))
+            out.append(cand.cost)
+        return out
+
+    def _ensure_geometry(self, images: torch.Tensor) -> None:
+        """Input shape and dtype of every convolution for this batch geometry (one hooked forward)."""
+        shape = tuple(images.shape)
+        if self._geometry_for == shape:
+            return
+        self._geometry = {}
+        hooks = [m.register_forward_hook(
+            lambda mod, inp, out: self._geometry.__setitem__(mod, (tuple(inp[0].shape), inp[0].dtype)))
+            for m in self.model.modules() if isinstance(m, nn.Conv2d)]
+        try:
+            with self.session():
+                self.forward(images)
+        finally:
+            for h in hooks:
+                h.remove()
+        self._geometry_for = shape
 
     # -- host preparation for a set of candidates: plans + one shared index upload
     def prepare(self, indices: Sequence[int]) -> None:
@@ -113,19 +190,7 @@ class SensitivitySweep:
         Doing the lookups on a helper thread instead does not pay: they wait for the device queue the
         evaluation loop keeps full, and the loop ends up waiting for the helper.  Returns the number
         of problems warmed."""
-        shape = tuple(images.shape)
-        if self._geometry_for != shape:
-            self._geometry = {}
-            hooks = [m.register_forward_hook(
-                lambda mod, inp, out: self._geometry.__setitem__(mod, (tuple(inp[0].shape), inp[0].dtype)))
-                for m in self.model.modules() if isinstance(m, nn.Conv2d)]
-            try:
-                with self.session():
-                    self.forward(images)
-            finally:
-                for h in hooks:
-                    h.remove()
-            self._geometry_for = shape
+        self._ensure_geometry(images)
         warmed = 0
         for i in indices:
             if i not in self.jobs:
@@ -196,19 +261,27 @@ class SensitivitySweep:
         n = len(self.candidates)
         indices = list(range(n)) if indices is None else list(indices)
         rank, world = sdist.world()
-        costs = [self.candidates[i].cost for i in indices]
+        all_costs = self.candidate_costs(images)
+        costs = [all_costs[i] for i in indices]
         parts = sdist.partition_by_cost(costs, world)
         mine = [indices[k] for k in parts[rank]]
         self.prepare(mine)
         self.warm_shapes(images, mine)
+        self.last_share = {"candidates": len(mine), "cost": float(sum(all_costs[i] for i in mine))}
         c = self.num_classes
         table = torch.zeros(n, c, c, dtype=torch.int64, device=self.device)
         kd = torch.zeros(n, 3, dtype=torch.float32, device=self.device)
+        import time
+        t0 = time.perf_counter()
         with self.session():
             teacher = self.forward(images).float().contiguous() if with_kd else None
-            sdist.sharded_tables(n, indices, costs,
-                                 lambda i: self.evaluate(i, images, labels, teacher, table[i], kd[i] if with_kd else None),
-                                 [table, kd] if with_kd else [table])
+            for i in mine:   # no communication before the final all-reduce
+                self.evaluate(i, images, labels, teacher, table[i], kd[i] if with_kd else None)
+            if world > 1:
+                torch.cuda.synchronize(self.device)   # this rank's own work, for the busy / idle split
+            self.last_share["busy_s"] = time.perf_counter() - t0
+            for t in ([table, kd] if with_kd else [table]):
+                sdist.all_reduce_sum_(t)
         return {"confusion": table, "kd": kd, "miou": miou_from_confusion(table)}
 
 

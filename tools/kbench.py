@@ -51,7 +51,8 @@ def main():
     dev = torch.device("cuda:0")
     want = lambda n: not only or n in only
 
-    if want("importance") or want("taylor") or want("gather"):
+    cols_only = "gather_cols" in only   # the rows + columns case alone (its own kernel-name statistics)
+    if want("importance") or want("taylor") or want("gather") or cols_only:
         shapes = synth.deeplab_resnet50_conv_shapes(21)
         sizes = [o * i * kh * kw for o, i, kh, kw in shapes]
         offs, pos = [], 0
@@ -87,7 +88,7 @@ def main():
             fns = [lambda w=w, g=g: plan.run([w], [g], score, nat.IMP_TAYLOR, True)
                    for w, g in zip(ws, gs)]
             report("importance_taylor", timed(fns, args.iters), plan.algorithmic_bytes(nat.IMP_TAYLOR))
-        if want("gather"):
+        if want("gather") and not cols_only:
             for label, pick in (("gather_out50", lambda o: np.arange(0, o, 2, dtype=np.int64)),
                                 ("gather_first_half", lambda o: np.arange(0, (o + 1) // 2, dtype=np.int64))):
                 specs, idx, dpos, ipos = [], [], 0, 0
@@ -103,6 +104,7 @@ def main():
                 fns = [lambda w=w, d=d: gplan.run([w], d, idx_t) for w, d in zip(ws, dsts)]
                 report(f"{label} ({gplan.n_items} items)", timed(fns, args.iters), gplan.algorithmic_bytes())
                 del dsts
+        if want("gather") or cols_only:
             # both lists, as in a whole-model pruning step: every second out-channel AND in-channel
             specs, idx, dpos, ipos = [], [], 0, 0
             for (o, i, kh, kw), off in zip(shapes, offs):
@@ -160,8 +162,10 @@ def main():
         report("argmax_confusion fp32 C=5", timed(fns, args.iters), P * (c * 4 + 8))
         del sets
 
-    if want("confusion"):
+    if want("confusion") or "confusion_small" in only:
         for (n, h, w, c, copies, tag) in ((8, 512, 512, 21, 10, "cfg1"), (32, 1024, 2048, 19, 1, "cfg5")):
+            if "confusion_small" in only and tag != "cfg1":
+                continue
             for kind in ("uniform", "blocky"):
                 lab = synth.label_map(5, n, h, w, c, kind, ignore_share=0.10 if tag == "cfg5" else 0.05)
                 pred = synth.predictions_from(lab, 5, c)
@@ -169,7 +173,7 @@ def main():
                 sets = [(tp.clone(), tl.clone()) for _ in range(copies)]
                 conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
                 fns = [lambda a=a: ops.confusion_update(conf, a[0], a[1], c) for a in sets]
-                report(f"confusion_{tag}_{kind} (hist+reduce)", timed(fns, args.iters), n * h * w * 16)
+                report(f"confusion_{tag}_{kind} (one launch)", timed(fns, args.iters), n * h * w * 16)
                 del sets
 
     if want("argmax"):

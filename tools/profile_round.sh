@@ -1,0 +1,26 @@
+#!/bin/bash
+# The round's measurement pass on the GPU box: kernel traces and the two PMC passes, summaries into
+# gpurun_out/prof_<tag>/ (copy what is to be kept into profiles/).  Usage: tools/profile_round.sh r02
+set -e
+TAG=${1:-rXX}
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+# 1. every kernel alone, per-dispatch trace
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kbench" -o kb -- python3 tools/kbench.py --iters 25 > "$OUT/kbench.log" 2>&1
+python3 tools/trace_medians.py "$OUT/kbench" > "$OUT/kbench_medians.txt"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kbench_fwd" -o kb -- python3 tools/kbench.py --only upsample,depthwise,bnact --iters 25 > "$OUT/kbench_fwd.log" 2>&1
+python3 tools/trace_medians.py "$OUT/kbench_fwd" > "$OUT/kbench_fwd_medians.txt"
+# 2. the bench command itself
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o bench -- python3 bench.py --no-cpu-baseline > "$OUT/bench_line.json" 2> "$OUT/bench.err"
+python3 tools/trace_medians.py "$OUT/bench" > "$OUT/bench_medians.txt"
+# 3. HBM traffic: one counter per pass, nothing else traced
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 tools/kbench.py --iters 6 > "$OUT/pmc_fetch.log" 2>&1
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 tools/kbench.py --iters 6 > "$OUT/pmc_write.log" 2>&1
+python3 tools/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" > "$OUT/pmc_traffic.json"
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_small" -- python3 tools/kbench.py --only gather_cols,confusion_small --iters 6 > "$OUT/pmc_fetch_small.log" 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_small" -- python3 tools/kbench.py --only gather_cols,confusion_small --iters 6 > "$OUT/pmc_write_small.log" 2>&1
+python3 tools/pmc_summary.py "$OUT/pmc_fetch_small" "$OUT/pmc_write_small" > "$OUT/pmc_traffic_small_cases.json"
+rm -rf "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_fetch_small "$OUT"/pmc_write_small
+find "$OUT" -name "*kernel_trace.csv" -size +20M -delete
+echo profile pass done

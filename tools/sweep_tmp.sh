@@ -1,4 +1,8 @@
 set -e
-timeout -k 10 300 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread -k "gather or engine or config1" 2>&1 | tail -3
-for t in 4096 8192 16384; do echo "== STAGE_TARGET=$t"; SPICE_GATHER_STAGE_TARGET_ELEMS=$t tools/rocprof_kbench.sh gather r02_gq_$t 30 | grep -v "^ *n "; done
-for t in 2048 4096; do echo "== ROWS TARGET=$t"; SPICE_GATHER_TARGET_ELEMS=$t tools/rocprof_kbench.sh gather r02_gr_$t 30 | grep -v "^ *n "; done
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout -k 10 400 python bench.py > gpurun_out/bench_weak.json 2> gpurun_out/bench_weak.err
+tail -c 3000 gpurun_out/bench_weak.json
+timeout -k 10 300 python bench.py --strong > gpurun_out/bench_strong_n1.json 2> gpurun_out/bench_strong_n1.err
+cat gpurun_out/bench_strong_n1.json
+SPICE_DIST_BACKEND=gloo timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --strong > gpurun_out/bench_strong_gloo2.json 2> gpurun_out/bench_strong_gloo2.err
+cat gpurun_out/bench_strong_gloo2.json

@@ -39,7 +39,9 @@ def compute_taylor_scores(model: nn.Module, dataloader, device: str, max_batches
     for m in convs:
         offsets.append(total)
         total += m.out_channels
-    flat = torch.zeros(max(total, 1), dtype=torch.float32, device=device)
+    # scores of every convolution, then one extra slot that carries the batch count through the same
+    # all-reduce (exact in fp32 far beyond any calibration set)
+    flat = torch.zeros(total + 1, dtype=torch.float32, device=device)
     rank, world = 0, 1
     if shard and torch.distributed.is_available() and torch.distributed.is_initialized():
         rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
@@ -82,11 +84,10 @@ def compute_taylor_scores(model: nn.Module, dataloader, device: str, max_batches
         seen += 1
 
     if world > 1:
-        counter = torch.tensor([float(seen)], device=device)
-        sdist.all_reduce_sum_(flat)
-        sdist.all_reduce_sum_(counter)
-        seen = int(counter.item())
-    flat = flat / max(seen, 1)
+        flat[total] = float(seen)
+        sdist.all_reduce_sum_(flat)   # the one exchange of the calibration pass
+        seen = int(round(float(flat[total].item())))
+    flat = flat[:total] / max(seen, 1)
     model.zero_grad(set_to_none=True)
     model.train(was_training)
     return {m: flat[o: o + m.out_channels] for m, o in zip(convs, offsets)}

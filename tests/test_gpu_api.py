@@ -143,10 +143,28 @@ def test_compute_taylor_scores_matches_reference(dev, tag, cls, bare, max_batche
     net.train()
     batches = [(torch.from_numpy(TY[f"batch{b}/images"]), torch.from_numpy(TY[f"batch{b}/targets"])) for b in range(3)]
     loader = [b[0] for b in batches] if bare else batches
-    scores = compute_taylor_scores(net, loader, str(dev), max_batches=max_batches)
+    # Two bars.  (1) The part this library computes - |g|*|w| summed per channel, accumulated over the
+    # batches, divided by their number - against an fp64 evaluation on the SAME device gradients: 1e-5.
+    # (2) The whole function against the scores the reference produced on the CPU: its forward and
+    # backward ran on torch's CPU kernels, here they run on MIOpen, so the gradients themselves differ
+    # in the last bits before any reduction happens: 2e-5.
+    from spice_amd.pruning import sensitivity_utils as su
+    exact = {}
+
+    def reduce_and_record(weights, grads, out, accumulate):
+        for k, (w, g) in enumerate(zip(weights, grads)):
+            term = (g.detach().double().abs() * w.detach().double().abs()).flatten(1).sum(1).cpu().numpy()
+            exact[k] = exact.get(k, 0) + term
+        exact["batches"] = exact.get("batches", 0) + 1
+        return su._hip_row_reduce(weights, grads, out, accumulate)
+
+    scores = compute_taylor_scores(net, loader, str(dev), max_batches=max_batches, _row_reduce=reduce_and_record)
     assert net.training and all(p.grad is None for p in net.parameters())
     by_name = dict(net.named_modules())
     assert len(scores) == 4
+    convs = [m for m in net.modules() if isinstance(m, torch.nn.Conv2d)]
+    for k, m in enumerate(convs):
+        np.testing.assert_allclose(scores[m].cpu().numpy(), exact[k] / exact["batches"], rtol=1e-5, atol=1e-12)
     for n in [str(x) for x in TY["conv_names"]]:
         got = scores[by_name[n]].cpu().numpy()
         np.testing.assert_allclose(got, TY[f"{tag}/{n}"], rtol=2e-5, atol=1e-9)

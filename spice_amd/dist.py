@@ -13,7 +13,8 @@ import torch.distributed as dist
 
 
 def init_from_env(backend: str = None) -> Tuple[int, int, int]:
-    """(rank, world, local_rank) from torchrun's environment; no-op for a single process.
+    """(rank, world, local_rank) from torchrun's environment; no-op for a single process
+    (unless SPICE_DIST_FORCE_INIT=1).
     SPICE_DIST_BACKEND overrides the backend (e.g. "gloo" to rehearse several ranks on one GPU:
     device tensors are then staged through the host in the helpers below); local_rank is folded
     onto the visible devices so that such a rehearsal maps every rank to an existing GPU."""
@@ -34,7 +35,10 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(
             os.environ.get("TMPDIR", "/tmp"), f"spice_miopen_{os.getuid()}_r{local}"))
         os.makedirs(os.environ["MIOPEN_USER_DB_PATH"], exist_ok=True)
-    if world > 1 and not dist.is_initialized():
+    # SPICE_DIST_FORCE_INIT=1 creates the process group for a single rank too (RCCL on one GPU: how the
+    # collective path is exercised where only one GPU is at hand)
+    force = os.environ.get("SPICE_DIST_FORCE_INIT", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

@@ -19,10 +19,9 @@ class _KDLiteFunction(torch.autograd.Function):
     actual upstream gradients when ce / kd are differentiated on their own."""
 
     @staticmethod
-    def forward(ctx, student, teacher, labels, opts):
-        # autograd runs forward() with grad mode off, so torch.is_grad_enabled() says nothing here;
-        # needs_input_grad is what tells whether a backward through the student will come
-        want = bool(ctx.needs_input_grad[0])
+    def forward(ctx, student, teacher, labels, opts, want):
+        # `want` (will a backward through the student come?) is decided by the caller, _apply below:
+        # autograd runs forward() with grad mode switched off, and needs_input_grad ignores torch.no_grad()
         ctx.set_materialize_grads(False)
         out3, grad, _ = ops.kdlite_forward(student.detach(), teacher.detach(), labels, want_grad=want, **opts)
         ctx.opts = opts
@@ -40,19 +39,24 @@ class _KDLiteFunction(torch.autograd.Function):
         student, teacher, labels = ctx.saved_tensors
         if g_ce is None and g_kd is None:
             if g_total is None:
-                return None, None, None, None
+                return None, None, None, None, None
             grad = ctx.saved_grad
             if grad is None:  # a second backward through the same graph: the first one consumed the buffer
                 _, grad, _ = ops.kdlite_forward(student.detach(), teacher.detach(), labels,
                                                 want_grad=True, **ctx.opts)
             ops.scale_inplace(grad, g_total.reshape(1).float().contiguous())
             ctx.saved_grad = None
-            return grad, None, None, None
+            return grad, None, None, None, None
         zero = torch.zeros(1, device=student.device)
         up = torch.cat([(g if g is not None else zero).reshape(1).float() for g in (g_total, g_ce, g_kd)])
         _, grad, _ = ops.kdlite_forward(student.detach(), teacher.detach(), labels, want_grad=True,
                                         upstream=up.contiguous(), **ctx.opts)
-        return grad, None, None, None
+        return grad, None, None, None, None
+
+
+def _apply(student, teacher, labels, opts):
+    want = torch.is_grad_enabled() and student.requires_grad
+    return _KDLiteFunction.apply(student, teacher, labels, opts, want)
 
 
 def _prepare(logits: torch.Tensor) -> torch.Tensor:
@@ -81,8 +85,7 @@ class KDLiteLoss(nn.Module):
         opts = dict(temperature=self.temperature, alpha=self.alpha, ignore_index=self.ignore_index,
                     boundary_weight=self.boundary_weight, confidence_weight=self.confidence_weight,
                     class_weight=self.ce_loss.class_weights)
-        total, ce, kd = _KDLiteFunction.apply(_prepare(student_logits), _prepare(teacher_logits),
-                                              labels.long().contiguous(), opts)
+        total, ce, kd = _apply(_prepare(student_logits), _prepare(teacher_logits), labels.long().contiguous(), opts)
         return {"total": total, "ce": ce, "kd": kd}
 
 
@@ -105,8 +108,7 @@ class PixelKDLoss(nn.Module):
                 "PixelKDLoss with a float mask is only available through KDLiteLoss "
                 "(boundary_weight / confidence_weight)")
         opts = dict(temperature=self.temperature, alpha=0.0, ignore_index=255)
-        _, _, kd = _KDLiteFunction.apply(_prepare(student_logits), _prepare(teacher_logits),
-                                         labels.contiguous(), opts)
+        _, _, kd = _apply(_prepare(student_logits), _prepare(teacher_logits), labels.contiguous(), opts)
         return kd
 
 
@@ -127,5 +129,5 @@ class SegmentationLoss(nn.Module):
                     class_weight=self.class_weights)
         p = _prepare(predictions)
         # alpha = 1: total == ce, and its gradient is the one the fused pass already wrote
-        total, _, _ = _KDLiteFunction.apply(p, p.detach(), targets.long().contiguous(), opts)
+        total, _, _ = _apply(p, p.detach(), targets.long().contiguous(), opts)
         return total

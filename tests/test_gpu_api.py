@@ -338,6 +338,21 @@ def test_two_rank_sharded_evaluation(dev, tmp_path):
     assert 0.0 <= ref["miou"] <= 1.0 and len(ref["per_class_iou"]) == 6
 
 
+def test_rccl_single_rank_collectives(dev):
+    """backend "nccl" (RCCL) on the one GPU at hand: process-group set-up through dist.init_from_env, the
+    int64 / fp32 / fp64 all-reduces of the sweep and the Taylor pass on device buffers, the asynchronous
+    bucketed gradient all-reduce.  With one rank the sums are identities; what is exercised is that RCCL
+    loads, initialises and runs this path's collectives on HIP memory (several GPUs are not available here)."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(__file__), "rccl_worker.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SPICE_DIST_BACKEND")}
+    env["MASTER_PORT"] = str(_free_port())
+    out = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "rccl ok" in out.stdout
+
+
 def test_cli_run_prints_summary_and_writes_run_directory(dev, tmp_path, capsys):
     """`python -m pruning.cli --model M --strategy S --ratio R ...` end to end at the reference's
     default geometry (5 classes, 576x576), one step, one epoch each."""

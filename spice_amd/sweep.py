@@ -75,7 +75,7 @@ class SensitivitySweep:
         self.jobs: Dict[int, SliceJob] = {}
         # when set to a list, evaluate() appends a (start, end) HIP event pair around each KD-Lite launch
         self.kd_events: Optional[list] = None
-        self._geometry, self._geometry_for, self._warmed = {}, None, set()
+        self._geometry, self._geometry_for, self._warmed, self._fresh_logits = {}, None, set(), None
 
     # -- cost of a candidate, for balancing ranks ---------------------------------------------
     #: share of a candidate's time that does not shrink with the network (host work per launch,
@@ -138,8 +138,10 @@ class SensitivitySweep:
         return out
 
     def _ensure_geometry(self, images: torch.Tensor) -> None:
-        """Input shape and dtype of every convolution for this batch geometry (one hooked forward)."""
+        """Input shape and dtype of every convolution for this batch geometry (one hooked forward of the
+        un-pruned network, whose logits are kept for run() to use as the teacher's)."""
         shape = tuple(images.shape)
+        self._fresh_logits = None
         if self._geometry_for == shape:
             return
         self._geometry = {}
@@ -148,7 +150,7 @@ class SensitivitySweep:
             for m in self.model.modules() if isinstance(m, nn.Conv2d)]
         try:
             with self.session():
-                self.forward(images)
+                self._fresh_logits = self.forward(images)
         finally:
             for h in hooks:
                 h.remove()
@@ -260,28 +262,46 @@ class SensitivitySweep:
         Returns {"confusion": [n,C,C] int64, "kd": [n,3] fp32, "miou": [n] fp64} (device tensors)."""
         n = len(self.candidates)
         indices = list(range(n)) if indices is None else list(indices)
+        import time
         rank, world = sdist.world()
+
+        def dev_sync():
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+
+        ph: Dict[str, float] = {}
+        t = time.perf_counter()
         all_costs = self.candidate_costs(images)
+        unpruned_logits, self._fresh_logits = self._fresh_logits, None   # this call's geometry pass, if it ran one
         costs = [all_costs[i] for i in indices]
         parts = sdist.partition_by_cost(costs, world)
         mine = [indices[k] for k in parts[rank]]
+        dev_sync()
+        ph["geometry_and_costs_s"], t = time.perf_counter() - t, time.perf_counter()
         self.prepare(mine)
+        dev_sync()
+        ph["plans_s"], t = time.perf_counter() - t, time.perf_counter()
         self.warm_shapes(images, mine)
-        self.last_share = {"candidates": len(mine), "cost": float(sum(all_costs[i] for i in mine))}
+        dev_sync()
+        ph["solver_lookups_s"], t = time.perf_counter() - t, time.perf_counter()
+        self.last_share = {"candidates": len(mine), "cost": float(sum(all_costs[i] for i in mine)), "phases": ph}
         c = self.num_classes
         table = torch.zeros(n, c, c, dtype=torch.int64, device=self.device)
         kd = torch.zeros(n, 3, dtype=torch.float32, device=self.device)
-        import time
         t0 = time.perf_counter()
         with self.session():
-            teacher = self.forward(images).float().contiguous() if with_kd else None
+            teacher = None
+            if with_kd:   # the un-pruned network's logits: the geometry pass of this call already computed them
+                teacher = (unpruned_logits if unpruned_logits is not None else self.forward(images)).float().contiguous()
+            dev_sync()
+            ph["teacher_forward_s"], t = time.perf_counter() - t, time.perf_counter()
             for i in mine:   # no communication before the final all-reduce
                 self.evaluate(i, images, labels, teacher, table[i], kd[i] if with_kd else None)
-            if world > 1:
-                torch.cuda.synchronize(self.device)   # this rank's own work, for the busy / idle split
+            dev_sync()   # this rank's own work, for the busy / idle split
+            ph["candidates_s"] = time.perf_counter() - t
             self.last_share["busy_s"] = time.perf_counter() - t0
-            for t in ([table, kd] if with_kd else [table]):
-                sdist.all_reduce_sum_(t)
+            for tb in ([table, kd] if with_kd else [table]):
+                sdist.all_reduce_sum_(tb)
         return {"confusion": table, "kd": kd, "miou": miou_from_confusion(table)}
 
 

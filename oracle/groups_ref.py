@@ -1,8 +1,9 @@
-"""Hand-declared coupled-channel groups of the two benchmark networks (test infrastructure; never
+"""Hand-declared coupled-channel groups of the six model names (test infrastructure; never
 imported by spice_amd/).
 
 What torch-pruning 1.6.0's DependencyGraph.get_all_groups(root_module_types=[Conv]) yields for
-smp 0.5.0's DeepLabV3Plus(resnet50) and Unet(timm-efficientnet-b3), as consumed by
+smp 0.5.0's DeepLabV3Plus / Unet / FPN on the resnet50 and timm-efficientnet-b3 encoders
+(pruning/model_configs.py:5-60), as consumed by
 `pruner.step()` (pruning/pruner.py:495), written down from the architectures themselves:
   * a convolution's output channels are tied to the batch-norm behind it, to every depthwise
     convolution and squeeze-excite gate applied to them, and to the input channels of every
@@ -44,14 +45,15 @@ def _own(table: Dict[str, Group]) -> None:
 
 
 # ------------------------------------------------------------------------------------------------
-# DeepLabV3Plus(resnet50, output_stride 16, separable ASPP 12/24/36, decoder 256, high-res 48)
+# encoders: each returns (table, taps) with taps[k] = root name of the channel set of feature k
+# (k = 1 .. 5 at strides 2 .. 32; feature 0 is the image itself)
 
-def deeplabv3plus_resnet50(classes: int) -> Dict[str, Group]:
-    t: Dict[str, Group] = {}
+def _resnet50_encoder(t: Dict[str, Group]) -> Dict[int, str]:
     e = "encoder."
-    # stem: conv1 -> bn1 -> (relu, max-pool) -> layer1.0.conv1 and the layer1.0 shortcut
+    # stem: conv1 -> bn1 -> (relu = feature 1, max-pool) -> layer1.0.conv1 and the layer1.0 shortcut
     t[e + "conv1"] = (Group(64).add(e + "conv1", "out").add(e + "bn1", "bn")
                       .add(e + "layer1.0.conv1", "in").add(e + "layer1.0.downsample.0", "in"))
+    taps = {1: e + "conv1"}
     blocks = {1: (3, 64), 2: (4, 128), 3: (6, 256), 4: (3, 512)}
     for layer, (n_blocks, width) in blocks.items():
         p = f"{e}layer{layer}."
@@ -70,39 +72,10 @@ def deeplabv3plus_resnet50(classes: int) -> Dict[str, Group]:
         if layer < 4:
             nxt = f"{e}layer{layer + 1}.0."
             res.add(nxt + "conv1", "in").add(nxt + "downsample.0", "in")
-        else:
-            a = "decoder.aspp.0.convs."
-            res.add(a + "0.0", "in")                       # 1x1 branch
-            for k in (1, 2, 3):                            # separable atrous branches: depthwise, then pointwise
-                res.add(f"{a}{k}.0.0", "dw").add(f"{a}{k}.0.1", "in")
-            res.add(a + "4.conv", "in")                    # image-pooling branch
         t[f"{p}0.conv3"] = res
-    # layer1's residual stream also feeds the decoder's high-resolution branch
-    t[e + "layer1.0.conv3"].add("decoder.block1.0", "in")
-    # ASPP: five 256-channel branches concatenated into the projection
-    a = "decoder.aspp.0."
-    branch_roots = (a + "convs.0.0", a + "convs.1.0.1", a + "convs.2.0.1", a + "convs.3.0.1", a + "convs.4.conv")
-    branch_bn = (a + "convs.0.1", a + "convs.1.1", a + "convs.2.1", a + "convs.3.1", a + "convs.4.bn")
-    for i, (root, bn) in enumerate(zip(branch_roots, branch_bn)):
-        t[root] = Group(256).add(root, "out").add(bn, "bn").add(a + "project.0", "in", branch_roots, i)
-    # projection -> bn -> (dropout) -> separable 3x3 (depthwise decoder.aspp.1.0, pointwise .1.1)
-    t[a + "project.0"] = (Group(256).add(a + "project.0", "out").add(a + "project.1", "bn")
-                          .add("decoder.aspp.1.0", "dw").add("decoder.aspp.1.1", "in"))
-    # fuse: cat(up-sampled ASPP output [256], high-res branch [48]) -> separable 3x3 (block2.0.0 dw, block2.0.1 pw)
-    cat = ("decoder.aspp.1.1", "decoder.block1.0")
-    t["decoder.aspp.1.1"] = (Group(256).add("decoder.aspp.1.1", "out").add("decoder.aspp.2", "bn")
-                             .add("decoder.block2.0.0", "dw", cat, 0).add("decoder.block2.0.1", "in", cat, 0))
-    t["decoder.block1.0"] = (Group(48).add("decoder.block1.0", "out").add("decoder.block1.1", "bn")
-                             .add("decoder.block2.0.0", "dw", cat, 1).add("decoder.block2.0.1", "in", cat, 1))
-    t["decoder.block2.0.1"] = (Group(256).add("decoder.block2.0.1", "out").add("decoder.block2.1", "bn")
-                               .add("segmentation_head.0", "in"))
-    t["segmentation_head.0"] = Group(classes, frozen=True).add("segmentation_head.0", "out")
-    _own(t)
-    return t
+        taps[layer + 1] = f"{p}0.conv3"
+    return taps
 
-
-# ------------------------------------------------------------------------------------------------
-# Unet(timm-efficientnet-b3, decoder (256,128,64,32,16)), skips at encoder widths (40, 32, 48, 136), head 3x3
 
 # stage: (block type, repeats, output width) after width 1.2 / depth 1.4 scaling of EfficientNet-B0
 _B3_STAGES = (("ds", 2, 24), ("ir", 3, 32), ("ir", 3, 48), ("ir", 5, 96), ("ir", 5, 136), ("ir", 6, 232), ("ir", 2, 384))
@@ -113,14 +86,13 @@ def _se_width(block_in: int) -> int:
     return max(1, round(block_in * 0.25))
 
 
-def unet_efficientnet_b3(classes: int) -> Dict[str, Group]:
-    t: Dict[str, Group] = {}
+def _efficientnet_b3_encoder(t: Dict[str, Group]) -> Dict[int, str]:
     e = "encoder."
     # the channel set every block's input lives in: (root name, Group)
     stream_root, stream = e + "conv_stem", Group(_B3_STEM)
     stream.add(e + "conv_stem", "out").add(e + "bn1", "bn")
     t[stream_root] = stream
-    skips = {}  # decoder block index -> (root of the skip's channel set)
+    taps = {1: stream_root}
     width_in = _B3_STEM
     for s, (kind, repeats, width_out) in enumerate(_B3_STAGES):
         for b in range(repeats):
@@ -152,19 +124,52 @@ def unet_efficientnet_b3(classes: int) -> Dict[str, Group]:
                     t[stream_root] = stream
                 stream.add(p + "conv_pwl", "out").add(p + "bn3", "bn")
             width_in = width_out
-        # feature taps of the U-Net: stem (/2), stage 1 (/4), stage 2 (/8), stage 4 (/16), stage 6 (/32 = head of the decoder)
-        if s == 1:
-            skips[2] = stream_root
-        elif s == 2:
-            skips[1] = stream_root
-        elif s == 4:
-            skips[0] = stream_root
-        elif s == 6:
-            bottom = stream_root
-    skips[3] = e + "conv_stem"
-    # decoder: block k = cat(up-sampled previous [prev], skip) -> conv1(3x3)+bn -> conv2(3x3)+bn; block 4 has no skip
+        # feature taps: stage 1 (/4), stage 2 (/8), stage 4 (/16), stage 6 (/32)
+        if s in (1, 2, 4, 6):
+            taps[{1: 2, 2: 3, 4: 4, 6: 5}[s]] = stream_root
+    return taps
+
+
+_ENCODERS = {"resnet50": _resnet50_encoder, "timm-efficientnet-b3": _efficientnet_b3_encoder}
+
+
+# ------------------------------------------------------------------------------------------------
+# decoders: attach the readers of the encoder's features, then their own groups
+
+def _deeplabv3plus_decoder(t: Dict[str, Group], taps: Dict[int, str], classes: int) -> None:
+    """smp DeepLabV3Plus: separable ASPP (12/24/36) on feature 5, 48-channel branch on feature 2, decoder 256."""
+    a = "decoder.aspp.0."
+    deep = t[taps[5]]
+    deep.add(a + "convs.0.0", "in")                               # 1x1 branch
+    for k in (1, 2, 3):                                           # separable atrous branches: depthwise, then pointwise
+        deep.add(f"{a}convs.{k}.0.0", "dw").add(f"{a}convs.{k}.0.1", "in")
+    deep.add(a + "convs.4.conv", "in")                            # image-pooling branch
+    t[taps[2]].add("decoder.block1.0", "in")                      # high-resolution branch
+    # five 256-channel branches concatenated into the projection
+    branch_roots = (a + "convs.0.0", a + "convs.1.0.1", a + "convs.2.0.1", a + "convs.3.0.1", a + "convs.4.conv")
+    branch_bn = (a + "convs.0.1", a + "convs.1.1", a + "convs.2.1", a + "convs.3.1", a + "convs.4.bn")
+    for i, (root, bn) in enumerate(zip(branch_roots, branch_bn)):
+        t[root] = Group(256).add(root, "out").add(bn, "bn").add(a + "project.0", "in", branch_roots, i)
+    # projection -> bn -> (dropout) -> separable 3x3 (depthwise decoder.aspp.1.0, pointwise .1.1)
+    t[a + "project.0"] = (Group(256).add(a + "project.0", "out").add(a + "project.1", "bn")
+                          .add("decoder.aspp.1.0", "dw").add("decoder.aspp.1.1", "in"))
+    # fuse: cat(up-sampled ASPP output [256], high-res branch [48]) -> separable 3x3 (block2.0.0 dw, block2.0.1 pw)
+    cat = ("decoder.aspp.1.1", "decoder.block1.0")
+    t["decoder.aspp.1.1"] = (Group(256).add("decoder.aspp.1.1", "out").add("decoder.aspp.2", "bn")
+                             .add("decoder.block2.0.0", "dw", cat, 0).add("decoder.block2.0.1", "in", cat, 0))
+    t["decoder.block1.0"] = (Group(48).add("decoder.block1.0", "out").add("decoder.block1.1", "bn")
+                             .add("decoder.block2.0.0", "dw", cat, 1).add("decoder.block2.0.1", "in", cat, 1))
+    t["decoder.block2.0.1"] = (Group(256).add("decoder.block2.0.1", "out").add("decoder.block2.1", "bn")
+                               .add("segmentation_head.0", "in"))
+    t["segmentation_head.0"] = Group(classes, frozen=True).add("segmentation_head.0", "out")
+
+
+def _unet_decoder(t: Dict[str, Group], taps: Dict[int, str], classes: int) -> None:
+    """smp Unet, decoder (256,128,64,32,16): block k = cat(up-sampled previous, skip) -> conv1(3x3)+bn -> conv2(3x3)+bn;
+    skips are features 4, 3, 2, 1; the last block has none; head 3x3."""
     dec_widths = (256, 128, 64, 32, 16)
-    prev_root = bottom
+    skips = {0: taps[4], 1: taps[3], 2: taps[2], 3: taps[1]}
+    prev_root = taps[5]
     for k, w in enumerate(dec_widths):
         d = f"decoder.blocks.{k}."
         if k in skips:
@@ -178,12 +183,62 @@ def unet_efficientnet_b3(classes: int) -> Dict[str, Group]:
         prev_root = d + "conv2.0"
     t[prev_root].add("segmentation_head.0", "in")
     t["segmentation_head.0"] = Group(classes, frozen=True).add("segmentation_head.0", "out")
+
+
+def _fpn_decoder(t: Dict[str, Group], taps: Dict[int, str], classes: int) -> None:
+    """smp FPN, pyramid 256, segmentation 128: p5 = 1x1(feature 5); p4/p3/p2 = up(previous) + 1x1(feature 4/3/2), so the four
+    lateral convolutions share one set of 256 channels; four segmentation branches of 3x3 conv + GroupNorm(32) (+ x2
+    up-sampling), 3 / 2 / 1 / 1 convolutions deep, summed.  GroupNorm normalises channels in blocks, so every set of
+    channels it sees is frozen (never pruned); the sum ties the last convolution of every branch together."""
+    d = "decoder."
+    t[taps[5]].add(d + "p5", "in")
+    t[taps[4]].add(d + "p4.skip_conv", "in")
+    t[taps[3]].add(d + "p3.skip_conv", "in")
+    t[taps[2]].add(d + "p2.skip_conv", "in")
+    pyr = Group(256).add(d + "p5", "out")
+    for k in (4, 3, 2):
+        pyr.add(f"{d}p{k}.skip_conv", "out")
+    depth = (3, 2, 1, 1)   # convolutions in branch 0..3 (branch i reads p5, p4, p3, p2)
+    for i in range(4):
+        pyr.add(f"{d}seg_blocks.{i}.0.block.0", "in")
+    t[d + "p5"] = pyr
+    last = []
+    for i, n in enumerate(depth):
+        for j in range(n):
+            name = f"{d}seg_blocks.{i}.{j}.block.0"
+            if j == n - 1:
+                last.append(name)
+            else:
+                t[name] = Group(128, frozen=True).add(name, "out").add(f"{d}seg_blocks.{i}.{j + 1}.block.0", "in")
+    merged = Group(128, frozen=True)
+    for name in last:
+        merged.add(name, "out")
+    merged.add("segmentation_head.0", "in")
+    t[last[0]] = merged
+    t["segmentation_head.0"] = Group(classes, frozen=True).add("segmentation_head.0", "out")
+
+
+_DECODERS = {"DeepLabV3Plus": _deeplabv3plus_decoder, "Unet": _unet_decoder, "FPN": _fpn_decoder}
+
+
+def table_for(arch: str, encoder: str, classes: int) -> Dict[str, Group]:
+    t: Dict[str, Group] = {}
+    taps = _ENCODERS[encoder](t)
+    _DECODERS[arch](t, taps, classes)
     _own(t)
     return t
 
 
-TABLES = {("DeepLabV3Plus", "resnet50"): deeplabv3plus_resnet50,
-          ("Unet", "timm-efficientnet-b3"): unet_efficientnet_b3}
+def deeplabv3plus_resnet50(classes: int) -> Dict[str, Group]:
+    return table_for("DeepLabV3Plus", "resnet50", classes)
+
+
+def unet_efficientnet_b3(classes: int) -> Dict[str, Group]:
+    return table_for("Unet", "timm-efficientnet-b3", classes)
+
+
+# every (architecture, encoder) pair of pruning/model_configs.py:5-60
+TABLES = {(a, e): (lambda classes, a=a, e=e: table_for(a, e, classes)) for a in _DECODERS for e in _ENCODERS}
 
 
 # ------------------------------------------------------------------------------------------------

@@ -9,7 +9,6 @@ import torch.nn as nn
 
 from oracle import groups_ref, prune_ref
 from spice_amd import engine, nets
-from spice_amd.engine.depgraph import build_groups
 
 pytestmark = pytest.mark.gpu
 
@@ -34,11 +33,9 @@ def _make(arch, enc, classes=7, seed=0):
 
 
 def _oracle_groups(cpu_model, arch, enc, classes=7):
-    """Groups the CPU oracle prunes by: the hand-declared table of the two benchmark networks
-    (independent of the graph analysis under test); for the other four name combinations, which have
-    no table, the product's own analysis (their coupling is then only checked for consistency)."""
-    table = groups_ref.TABLES.get((arch, enc))
-    groups = groups_ref.instantiate(cpu_model, table(classes)) if table else build_groups(cpu_model)
+    """Groups the CPU oracle prunes by: the hand-declared table of the model (oracle/groups_ref.py),
+    independent of the graph analysis under test."""
+    groups = groups_ref.instantiate(cpu_model, groups_ref.TABLES[(arch, enc)](classes))
     return [g for g in groups if not g.frozen]
 
 
@@ -131,7 +128,7 @@ def test_lamp_taylor_and_random_criteria(dev):
     for m, xx, yy in ((cpu, x, y), (gpu, x.to(dev), y.to(dev))):
         nn.functional.cross_entropy(m(xx), yy).backward()
     g_groups = engine.MagnitudePruner(gpu, ignored_layers=_ignored(gpu)).prunable_groups()
-    c_groups = {g.root_name: g for g in build_groups(cpu) if not g.frozen}
+    c_groups = {g.root_name: g for g in _oracle_groups(cpu, "Unet", "resnet50")}
     lamp, taylor, rnd = engine.LAMPImportance(), engine.TaylorImportance(), engine.RandomImportance()
     checked = 0
     for g in g_groups:

@@ -282,11 +282,13 @@ def test_fused_modules_keep_torch_semantics_and_channel_coupling():
     assert torch.equal(w(img), f(img))
 
 
-@pytest.mark.parametrize("arch,enc", [("DeepLabV3Plus", "resnet50"), ("Unet", "timm-efficientnet-b3")])
+@pytest.mark.parametrize("arch,enc", [("DeepLabV3Plus", "resnet50"), ("Unet", "timm-efficientnet-b3"),
+                                      ("DeepLabV3Plus", "timm-efficientnet-b3"), ("Unet", "resnet50"),
+                                      ("FPN", "resnet50"), ("FPN", "timm-efficientnet-b3")])
 @pytest.mark.parametrize("classes", [21, 5])
 def test_graph_analysis_equals_hand_declared_groups(arch, enc, classes):
-    """engine.depgraph.build_groups against oracle/groups_ref.py, the coupled-channel groups of the two
-    benchmark networks written down from their architectures: same roots, sizes, frozen flags, members,
+    """engine.depgraph.build_groups against oracle/groups_ref.py, the coupled-channel groups of the six
+    model names written down from their architectures: same roots, sizes, frozen flags, members,
     member kinds and positions inside concatenations.  An over-merged or missing coupling shows up here."""
     from oracle import groups_ref
     from spice_amd import nets

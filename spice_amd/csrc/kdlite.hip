@@ -278,6 +278,63 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_prepass_kernel(KdArgs a) {
     block_sum_store<4>(acc, red, a.pre_partial + (long long)blockIdx.x * 4);
 }
 
+// The same normalisers when neither the boundary nor the confidence option is on: they depend on the
+// labels alone, so the pre-pass is a flat streaming count over all N*H*W labels (16-byte loads, eight
+// labels per lane in flight per step; default load policy: the main pass reads the labels again).
+constexpr int kKdCountMaxBlocks = 1024;
+
+__device__ __forceinline__ void kd_count_label(long long lab, const KdArgs &a, float &nv, float &ws) {
+    if (lab == a.ignore_index) return;
+    nv += 1.f;   // every pixel that is not ignored takes part in the distillation term
+    if (lab >= 0 && lab < a.C) ws += a.class_w ? a.class_w[lab] : 1.f;
+}
+
+__global__ __launch_bounds__(kKdThreads) void kdlite_label_count_kernel(KdArgs a) {
+    __shared__ double red[kKdThreads / 64][8];
+    const long long P = a.N * a.HW;
+    const long long stride = (long long)gridDim.x * kKdThreads;
+    const long long gtid = (long long)blockIdx.x * kKdThreads + threadIdx.x;
+    float nv = 0.f, ws = 0.f;   // a lane sees at most P / stride labels: exact in fp32 far beyond any image batch
+    const bool vec = (reinterpret_cast<uintptr_t>(a.labels) & 15u) == 0;
+    const long long P2 = vec ? (P >> 1) : 0;
+    const longlong2 *l2 = reinterpret_cast<const longlong2 *>(a.labels);
+    long long i = gtid;
+    for (; i + 3 * stride < P2; i += 4 * stride) {
+        const longlong2 x0 = l2[i], x1 = l2[i + stride], x2 = l2[i + 2 * stride], x3 = l2[i + 3 * stride];
+        kd_count_label(x0.x, a, nv, ws);
+        kd_count_label(x0.y, a, nv, ws);
+        kd_count_label(x1.x, a, nv, ws);
+        kd_count_label(x1.y, a, nv, ws);
+        kd_count_label(x2.x, a, nv, ws);
+        kd_count_label(x2.y, a, nv, ws);
+        kd_count_label(x3.x, a, nv, ws);
+        kd_count_label(x3.y, a, nv, ws);
+    }
+    for (; i < P2; i += stride) {
+        const longlong2 x0 = l2[i];
+        kd_count_label(x0.x, a, nv, ws);
+        kd_count_label(x0.y, a, nv, ws);
+    }
+    for (long long j = 2 * P2 + gtid; j < P; j += stride) kd_count_label(a.labels[j], a, nv, ws);
+    const double acc[4] = {(double)nv, (double)ws, 0.0, 0.0};
+    block_sum_store<4>(acc, red, a.pre_partial + (long long)blockIdx.x * 4);
+}
+
+// Launches the pre-pass that fits the options and records its workgroup count in `a` (the main kernel
+// sums that many rows of the table).
+template <int VEC>
+static void kd_launch_prepass(KdArgs &a, bool ext, hipStream_t st) {
+    if (ext) {
+        hipLaunchKernelGGL((kdlite_prepass_kernel<VEC, true>), dim3(a.pre_blocks), dim3(kKdThreads), 0, st, a);
+        return;
+    }
+    long long g = (a.N * a.HW + (long long)kKdThreads * 16 - 1) / ((long long)kKdThreads * 16);
+    if (g < 1) g = 1;
+    if (g > kKdCountMaxBlocks) g = kKdCountMaxBlocks;
+    a.pre_blocks = (int)g;
+    hipLaunchKernelGGL(kdlite_label_count_kernel, dim3((unsigned)g), dim3(kKdThreads), 0, st, a);
+}
+
 template <int VEC>
 struct PixStats {
     float ms[VEC], mt[VEC], zs[VEC], z1[VEC], zt[VEC], zt1[VEC], at[VEC], sy[VEC];
@@ -723,13 +780,10 @@ static int kd_stage_mode() { return (int)knob_kd_stage(); }
 static int kd_regs_mode() { return (int)knob_kd_regs(); }
 
 template <int VEC>
-static int kd_launch(const KdArgs &a, bool grad, bool ext, int blocks, hipStream_t st) {
+static int kd_launch(KdArgs a, bool grad, bool ext, int blocks, hipStream_t st) {
     const dim3 g(blocks), b(kKdThreads);
     if (grad) {
-        if (ext)
-            hipLaunchKernelGGL((kdlite_prepass_kernel<VEC, true>), dim3(a.pre_blocks), b, 0, st, a);
-        else
-            hipLaunchKernelGGL((kdlite_prepass_kernel<VEC, false>), dim3(a.pre_blocks), b, 0, st, a);
+        kd_launch_prepass<VEC>(a, ext, st);
         SPICE_LAUNCH_CHECK();
         if (ext)
             hipLaunchKernelGGL((kdlite_main_kernel<VEC, true, true, false>), g, b, 0, st, a);
@@ -747,17 +801,12 @@ static int kd_launch(const KdArgs &a, bool grad, bool ext, int blocks, hipStream
 
 // Gradient with the logits staged in LDS: one pixel per lane, so a workgroup's stage is
 // C * 2 * 256 * 4 bytes (43 KB at 21 classes: three workgroups per CU).
-static int kd_launch_staged(const KdArgs &a, bool ext, bool vec4, int blocks, size_t lds_bytes, hipStream_t st) {
+static int kd_launch_staged(KdArgs a, bool ext, bool vec4, int blocks, size_t lds_bytes, hipStream_t st) {
     const dim3 g(blocks), b(kKdThreads);
-    if (vec4) {  // the label pre-pass keeps its 16-byte accesses when the layout allows
-        if (ext)
-            hipLaunchKernelGGL((kdlite_prepass_kernel<4, true>), dim3(a.pre_blocks), b, 0, st, a);
-        else
-            hipLaunchKernelGGL((kdlite_prepass_kernel<4, false>), dim3(a.pre_blocks), b, 0, st, a);
-    } else if (ext)
-        hipLaunchKernelGGL((kdlite_prepass_kernel<1, true>), dim3(a.pre_blocks), b, 0, st, a);
+    if (vec4)  // the pre-pass keeps its 16-byte accesses when the layout allows
+        kd_launch_prepass<4>(a, ext, st);
     else
-        hipLaunchKernelGGL((kdlite_prepass_kernel<1, false>), dim3(a.pre_blocks), b, 0, st, a);
+        kd_launch_prepass<1>(a, ext, st);
     SPICE_LAUNCH_CHECK();
     if (ext)
         hipLaunchKernelGGL((kdlite_main_kernel<1, true, true, true>), g, b, lds_bytes, st, a);
@@ -768,12 +817,9 @@ static int kd_launch_staged(const KdArgs &a, bool ext, bool vec4, int blocks, si
 }
 
 // Gradient with the logits kept in registers (C <= 8, 16-byte layout): label pre-pass + one pass.
-static int kd_launch_regs(const KdArgs &a, bool ext, int blocks, hipStream_t st) {
+static int kd_launch_regs(KdArgs a, bool ext, int blocks, hipStream_t st) {
     const dim3 g(blocks), b(kKdThreads);
-    if (ext)
-        hipLaunchKernelGGL((kdlite_prepass_kernel<4, true>), dim3(a.pre_blocks), b, 0, st, a);
-    else
-        hipLaunchKernelGGL((kdlite_prepass_kernel<4, false>), dim3(a.pre_blocks), b, 0, st, a);
+    kd_launch_prepass<4>(a, ext, st);
     SPICE_LAUNCH_CHECK();
     if (ext)
         hipLaunchKernelGGL((kdlite_grad_regs_kernel<true>), g, b, 0, st, a);

@@ -301,6 +301,17 @@ int spice_bn_act(const void *x, const void *residual, void *y, int32_t dtype, co
                  const float *var, const float *weight, const float *bias, float eps, int64_t n,
                  int64_t c, int64_t hw, int32_t relu, void *stream);
 
+/* The same for a residual block with a projection shortcut (the first bottleneck of every ResNet stage),
+ * whose shortcut has a batch-norm of its own:
+ *   y = relu?( bn(x) + bn_r(residual) )
+ * replacing batch_norm(residual) -> batch_norm(x) -> add -> relu.  bn_r(residual) is rounded to `dtype` where
+ * its own kernel would have stored it, so the values are those of the four separate launches.
+ * The four r_* vectors are fp32 [c]; residual must not be NULL. */
+int spice_bn_act_dual(const void *x, const void *residual, void *y, int32_t dtype, const float *mean,
+                      const float *var, const float *weight, const float *bias, float eps, const float *r_mean,
+                      const float *r_var, const float *r_weight, const float *r_bias, float r_eps, int64_t n,
+                      int64_t c, int64_t hw, int32_t relu, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * (7) Depthwise 3x3 convolution (stride 1, padding 1, no bias), fp16 NCHW.
  *

@@ -20,3 +20,12 @@ def bn_act(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, weight: torch
     if relu:
         y = torch.relu(y)
     return y
+
+
+def bn_act_dual(x: torch.Tensor, bn, residual: torch.Tensor, res_bn, relu: bool = False) -> torch.Tensor:
+    """relu?(bn(x) + res_bn(residual)) as four separate ops, each result rounded to the tensor's dtype:
+    the tail of a residual block whose shortcut is a projection followed by its own batch-norm.
+    `bn`, `res_bn`: (mean, var, weight, bias, eps) tuples."""
+    dtype = x.dtype
+    r = bn_act(residual, *res_bn)
+    return bn_act(x, *bn, residual=r.to(dtype), relu=relu)

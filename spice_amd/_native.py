@@ -92,6 +92,9 @@ SIGNATURES = {
     "spice_gather_run": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "spice_bn_act": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                c_int64, c_int64, c_int64, c_int32, c_void_p]),
+    "spice_bn_act_dual": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int64, c_int64, c_int32,
+                                    c_void_p]),
     "spice_depthwise_conv3x3": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int64, c_int32, c_int32,
                                           c_void_p]),
     "spice_depthwise_conv3x3_dilated": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int64, c_int32,

@@ -1,5 +1,6 @@
 // Inference batch-norm with the element-wise tail of a residual block fused in:
-//   y = relu?( bn(x) [+ residual] )
+//   y = relu?( bn(x) [+ residual] )      or, for a block with a projection shortcut,
+//   y = relu?( bn(x) + bn_r(residual) )  (the shortcut's own batch-norm, rounded where its kernel would store)
 // for NCHW tensors, replacing three launches of the forward of the models of
 // pruning/models.py:35-39 (MIOpen's batch-norm, torch's add, torch's clamp) by one that reads x (and the
 // residual) once and writes y once.
@@ -25,7 +26,8 @@ struct BnArgs {
     const void *res;
     void *y;
     const float *mean, *var, *weight, *bias;
-    float eps;
+    const float *r_mean, *r_var, *r_weight, *r_bias;   // batch-norm of the residual (RES_BN), else unused
+    float eps, r_eps;
     unsigned total;   // elements
     unsigned n_vec;   // total / VEC
     unsigned hw, c;
@@ -45,6 +47,15 @@ __device__ __forceinline__ BnChannel bn_channel(const BnArgs &a, unsigned ch) {
     return p;
 }
 
+__device__ __forceinline__ BnChannel bn_channel_res(const BnArgs &a, unsigned ch) {
+    BnChannel p;
+    p.mean = a.r_mean[ch];
+    p.inv = __builtin_amdgcn_rsqf(fabsf(a.r_var[ch] + a.r_eps));
+    p.weight = a.r_weight[ch];
+    p.bias = a.r_bias[ch];
+    return p;
+}
+
 // round to the storage type and come back, so that later steps see what a separate kernel would read
 template <typename T>
 __device__ __forceinline__ float round_trip(float v);
@@ -61,7 +72,7 @@ struct Pack {
     typedef T type __attribute__((ext_vector_type(VEC)));
 };
 
-template <typename T, int VEC, bool HAS_RES>
+template <typename T, int VEC, bool HAS_RES, bool RES_BN>
 __device__ __forceinline__ void bn_vector(const BnArgs &a, typename Pack<T, VEC>::type xv,
                                           typename Pack<T, VEC>::type rv, unsigned idx,
                                           typename Pack<T, VEC>::type *out) {
@@ -71,6 +82,11 @@ __device__ __forceinline__ void bn_vector(const BnArgs &a, typename Pack<T, VEC>
     const unsigned ch1 = ch0 + 1 == a.c ? 0 : ch0 + 1;
     const BnChannel p0 = bn_channel(a, ch0);
     const BnChannel p1 = bn_channel(a, ch1);   // a vector spans at most two planes (hw >= VEC)
+    BnChannel q0 = p0, q1 = p1;
+    if constexpr (RES_BN) {
+        q0 = bn_channel_res(a, ch0);
+        q1 = bn_channel_res(a, ch1);
+    }
     typename Pack<T, VEC>::type o;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -79,14 +95,22 @@ __device__ __forceinline__ void bn_vector(const BnArgs &a, typename Pack<T, VEC>
         const float w = next ? p1.weight : p0.weight, b = next ? p1.bias : p0.bias;
         const float t = (static_cast<float>(xv[e]) - m) * inv;
         float v = round_trip<T>(__builtin_fmaf(w, t, b));
-        if constexpr (HAS_RES) v = round_trip<T>(v + static_cast<float>(rv[e]));
+        if constexpr (HAS_RES) {
+            float r = static_cast<float>(rv[e]);
+            if constexpr (RES_BN) {   // the shortcut's batch-norm, stored in T by its own kernel before the add
+                const float rm = next ? q1.mean : q0.mean, rinv = next ? q1.inv : q0.inv;
+                const float rw = next ? q1.weight : q0.weight, rb = next ? q1.bias : q0.bias;
+                r = round_trip<T>(__builtin_fmaf(rw, (r - rm) * rinv, rb));
+            }
+            v = round_trip<T>(v + r);
+        }
         if (a.relu) v = v != v ? v : fmaxf(v, 0.0f);
         o[e] = static_cast<T>(v);
     }
     *out = o;
 }
 
-template <typename T, int VEC, bool HAS_RES>
+template <typename T, int VEC, bool HAS_RES, bool RES_BN>
 __global__ __launch_bounds__(kBnThreads) void bn_act_kernel(BnArgs a) {
     typedef typename Pack<T, VEC>::type vec_t;
     const vec_t *x = static_cast<const vec_t *>(a.x);
@@ -105,7 +129,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_kernel(BnArgs a) {
 #pragma unroll
         for (int u = 0; u < kBnVecPerLane; ++u) {
             const unsigned v = first + u * kBnThreads;
-            bn_vector<T, VEC, HAS_RES>(a, xv[u], rv[u], v * VEC, y + v);
+            bn_vector<T, VEC, HAS_RES, RES_BN>(a, xv[u], rv[u], v * VEC, y + v);
         }
     } else {
         for (int u = 0; u < kBnVecPerLane; ++u) {
@@ -113,7 +137,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_kernel(BnArgs a) {
             if (v < a.n_vec) {
                 vec_t rv = x[v];
                 if constexpr (HAS_RES) rv = r[v];
-                bn_vector<T, VEC, HAS_RES>(a, x[v], rv, v * VEC, y + v);
+                bn_vector<T, VEC, HAS_RES, RES_BN>(a, x[v], rv, v * VEC, y + v);
             }
         }
     }
@@ -123,19 +147,22 @@ template <typename T, int VEC>
 static int launch_bn(const BnArgs &a, hipStream_t st) {
     const unsigned per_block = kBnThreads * kBnVecPerLane;
     const dim3 grid((a.n_vec + per_block - 1) / per_block);
-    if (a.res != nullptr)
-        hipLaunchKernelGGL((bn_act_kernel<T, VEC, true>), grid, dim3(kBnThreads), 0, st, a);
+    if (a.res != nullptr && a.r_mean != nullptr)
+        hipLaunchKernelGGL((bn_act_kernel<T, VEC, true, true>), grid, dim3(kBnThreads), 0, st, a);
+    else if (a.res != nullptr)
+        hipLaunchKernelGGL((bn_act_kernel<T, VEC, true, false>), grid, dim3(kBnThreads), 0, st, a);
     else
-        hipLaunchKernelGGL((bn_act_kernel<T, VEC, false>), grid, dim3(kBnThreads), 0, st, a);
+        hipLaunchKernelGGL((bn_act_kernel<T, VEC, false, false>), grid, dim3(kBnThreads), 0, st, a);
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;
 }
 
 }  // namespace spice
 
-extern "C" int spice_bn_act(const void *x, const void *residual, void *y, int32_t dtype, const float *mean,
-                            const float *var, const float *weight, const float *bias, float eps, int64_t n,
-                            int64_t c, int64_t hw, int32_t relu, void *stream) {
+static int bn_act_launch(const void *x, const void *residual, void *y, int32_t dtype, const float *mean,
+                         const float *var, const float *weight, const float *bias, float eps, const float *r_mean,
+                         const float *r_var, const float *r_weight, const float *r_bias, float r_eps, int64_t n,
+                         int64_t c, int64_t hw, int32_t relu, void *stream) {
     using namespace spice;
     if (n < 0 || c <= 0 || hw <= 0) return SPICE_ERR_ARG;
     if (n == 0) return SPICE_OK;
@@ -157,6 +184,11 @@ extern "C" int spice_bn_act(const void *x, const void *residual, void *y, int32_
     a.weight = weight;
     a.bias = bias;
     a.eps = eps;
+    a.r_mean = r_mean;
+    a.r_var = r_var;
+    a.r_weight = r_weight;
+    a.r_bias = r_bias;
+    a.r_eps = r_eps;
     a.total = static_cast<unsigned>(total);
     a.n_vec = static_cast<unsigned>(wide ? total / vec : total);
     a.hw = static_cast<unsigned>(hw);
@@ -165,4 +197,21 @@ extern "C" int spice_bn_act(const void *x, const void *residual, void *y, int32_
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == 1) return wide ? launch_bn<_Float16, 8>(a, st) : launch_bn<_Float16, 1>(a, st);
     return wide ? launch_bn<float, 4>(a, st) : launch_bn<float, 1>(a, st);
+}
+
+extern "C" int spice_bn_act(const void *x, const void *residual, void *y, int32_t dtype, const float *mean,
+                            const float *var, const float *weight, const float *bias, float eps, int64_t n,
+                            int64_t c, int64_t hw, int32_t relu, void *stream) {
+    return bn_act_launch(x, residual, y, dtype, mean, var, weight, bias, eps, nullptr, nullptr, nullptr, nullptr, 0.0f, n,
+                         c, hw, relu, stream);
+}
+
+extern "C" int spice_bn_act_dual(const void *x, const void *residual, void *y, int32_t dtype, const float *mean,
+                                 const float *var, const float *weight, const float *bias, float eps,
+                                 const float *r_mean, const float *r_var, const float *r_weight, const float *r_bias,
+                                 float r_eps, int64_t n, int64_t c, int64_t hw, int32_t relu, void *stream) {
+    if (residual == nullptr || r_mean == nullptr || r_var == nullptr || r_weight == nullptr || r_bias == nullptr)
+        return SPICE_ERR_ARG;
+    return bn_act_launch(x, residual, y, dtype, mean, var, weight, bias, eps, r_mean, r_var, r_weight, r_bias, r_eps, n, c,
+                         hw, relu, stream);
 }

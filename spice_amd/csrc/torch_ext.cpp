@@ -310,6 +310,33 @@ Tensor bn_act(const Tensor &x, const Tensor &mean, const Tensor &var, const Tens
     return out;
 }
 
+Tensor bn_act_dual(const Tensor &x, const Tensor &mean, const Tensor &var, const Tensor &weight, const Tensor &bias,
+                   double eps, const Tensor &residual, const Tensor &r_mean, const Tensor &r_var, const Tensor &r_weight,
+                   const Tensor &r_bias, double r_eps, bool relu) {
+    const int32_t code = act_code(x, "bn_act_dual");
+    TORCH_CHECK(x.is_cuda(), "x is on ", x.device(),
+                "; the MI355X path has no CPU implementation (move the tensor to a HIP device)");
+    TORCH_CHECK_VALUE(x.dim() == 4 && x.is_contiguous(), "bn_act_dual: x must be a contiguous [N, C, H, W] tensor");
+    const int64_t c = x.size(1);
+    for (const Tensor *t : {&mean, &var, &weight, &bias, &r_mean, &r_var, &r_weight, &r_bias})
+        TORCH_CHECK_TYPE(t->scalar_type() == at::kFloat && t->device() == x.device() && t->numel() == c &&
+                             t->is_contiguous(),
+                         "bn_act_dual: the eight parameter vectors must be contiguous fp32 [", c, "] on ", x.device());
+    TORCH_CHECK_VALUE(residual.sizes() == x.sizes(), "bn_act_dual: residual must have x's shape");
+    TORCH_CHECK_TYPE(residual.scalar_type() == x.scalar_type() && residual.device() == x.device() &&
+                         residual.is_contiguous(),
+                     "bn_act_dual: residual must be contiguous, of x's dtype and on x's device");
+    c10::DeviceGuard guard(x.device());
+    Tensor out = at::empty_like(x);
+    check_rc(spice_bn_act_dual(x.data_ptr(), residual.data_ptr(), out.data_ptr(), code, mean.data_ptr<float>(),
+                               var.data_ptr<float>(), weight.data_ptr<float>(), bias.data_ptr<float>(), (float)eps,
+                               r_mean.data_ptr<float>(), r_var.data_ptr<float>(), r_weight.data_ptr<float>(),
+                               r_bias.data_ptr<float>(), (float)r_eps, x.size(0), c, x.size(2) * x.size(3), relu ? 1 : 0,
+                               current_stream(x)),
+             "spice_bn_act_dual");
+    return out;
+}
+
 Tensor depthwise_conv3x3(const Tensor &x, const Tensor &weight, int64_t dilation) {
     check_dev(x, "x", at::kHalf);
     TORCH_CHECK_TYPE(weight.scalar_type() == at::kHalf || weight.scalar_type() == at::kFloat,
@@ -380,6 +407,8 @@ TORCH_LIBRARY(spice, m) {
           "int out_dtype) -> Tensor", &upsample_bilinear);
     m.def("bn_act(Tensor x, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, Tensor? residual, "
           "bool relu) -> Tensor", &bn_act);
+    m.def("bn_act_dual(Tensor x, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, Tensor residual, "
+          "Tensor r_mean, Tensor r_var, Tensor r_weight, Tensor r_bias, float r_eps, bool relu) -> Tensor", &bn_act_dual);
     m.def("depthwise_conv3x3(Tensor x, Tensor weight, int dilation) -> Tensor", &depthwise_conv3x3);
     m.def("conv1x1_f16(Tensor x, Tensor weight2d) -> Tensor", &conv1x1_f16);
 }

@@ -40,17 +40,26 @@ class BatchNormAct2d(nn.BatchNorm2d):
         super().__init__(num_features, **kwargs)
         self.relu_after = relu
 
-    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                residual_norm: Optional[nn.BatchNorm2d] = None) -> torch.Tensor:
+        """`residual_norm`: a batch-norm still to be applied to `residual` (the shortcut of a residual block
+        with a projection): y = relu?( bn(x) + residual_norm(residual) ), one launch on the inference path."""
         inference = _LIBRARY_FORWARD and not (self.training or torch.is_grad_enabled()) and x.is_cuda
         if (inference and self.track_running_stats and self.affine and self.weight.dtype == torch.float32
                 and self.running_mean.dtype == torch.float32):
             if ops.bn_act_supported(x) and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape
                                                                   and residual.is_contiguous())):
-                return ops.bn_act(x, self.running_mean, self.running_var, self.weight, self.bias, self.eps,
-                                  residual=residual, relu=self.relu_after)
+                if residual_norm is None:
+                    return ops.bn_act(x, self.running_mean, self.running_var, self.weight, self.bias, self.eps,
+                                      residual=residual, relu=self.relu_after)
+                if (residual is not None and not residual_norm.training and residual_norm.track_running_stats
+                        and residual_norm.affine and residual_norm.weight.dtype == torch.float32
+                        and residual_norm.running_mean.dtype == torch.float32
+                        and residual_norm.num_features == self.num_features):
+                    return ops.bn_act_dual(x, self, residual, residual_norm, relu=self.relu_after)
         y = super().forward(x)
         if residual is not None:
-            y = y + residual
+            y = y + (residual if residual_norm is None else residual_norm(residual))
         return F.relu(y) if self.relu_after else y
 
     def extra_repr(self) -> str:

@@ -30,8 +30,13 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         out = self.bn2(self.conv2(self.bn1(self.conv1(x))))
-        identity = x if self.downsample is None else self.downsample(x)
-        return self.bn3(self.conv3(out), identity)
+        if self.downsample is None:
+            return self.bn3(self.conv3(out), x)
+        if not isinstance(x, torch.Tensor):
+            # symbolic tracing (the channel-coupling analysis): the shortcut as the plain composition it is
+            return self.bn3(self.conv3(out), self.downsample(x))
+        # the shortcut's batch-norm rides along with bn3: relu(bn3(.) + bn_ds(conv_ds(x))) in one launch at inference
+        return self.bn3(self.conv3(out), self.downsample[0](x), self.downsample[1])
 
 
 class ResNet50Encoder(nn.Module):

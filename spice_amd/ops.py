@@ -429,6 +429,20 @@ def bn_act(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, weight: torch
     return _bn_fn(x, mean, var, weight, bias, eps, residual, relu)
 
 
+_bn_dual_fn = None
+
+
+def bn_act_dual(x: torch.Tensor, bn: "torch.nn.BatchNorm2d", residual: torch.Tensor, res_bn: "torch.nn.BatchNorm2d",
+                relu: bool = False) -> torch.Tensor:
+    """relu?(bn(x) + res_bn(residual)) with both modules' running statistics, in one launch: the tail of a
+    residual block whose shortcut is a projection with a batch-norm of its own."""
+    global _bn_dual_fn
+    if _bn_dual_fn is None:
+        _bn_dual_fn = spice_ops().bn_act_dual
+    return _bn_dual_fn(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, residual,
+                       res_bn.running_mean, res_bn.running_var, res_bn.weight, res_bn.bias, res_bn.eps, relu)
+
+
 def depthwise_conv3x3_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
     """fp16 NCHW input whose width is a multiple of 8 (at most 2048), [C,1,3,3] fp16 or fp32 weight."""
     return (x.dim() == 4 and x.dtype == torch.float16 and x.is_contiguous() and x.shape[3] % 8 == 0

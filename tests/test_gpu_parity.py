@@ -507,7 +507,8 @@ def test_model_forward_on_library_kernels_equals_torch_forward(dev):
         x = torch.randn(2, 3, 128, 128, device=dev)
         for cast in (True, False):
             seen = []
-            hooks = [m.register_forward_hook(lambda mod, i, o: seen.append((mod, [t.detach().clone() for t in i], o.detach().clone())))
+            keep = lambda t: t.detach().clone() if isinstance(t, torch.Tensor) else t   # a shortcut's batch-norm rides along as a module
+            hooks = [m.register_forward_hook(lambda mod, i, o: seen.append((mod, [keep(t) for t in i], o.detach().clone())))
                      for m in watched]
             with torch.autocast("cuda", dtype=torch.float16, enabled=cast):
                 with torch.no_grad():
@@ -681,6 +682,68 @@ def test_bn_act_vs_oracle_and_torch(dev, shape, dtype, with_res, relu):
     if relu:
         there = torch.relu(there)
     assert torch.equal(got, there)
+
+
+@pytest.mark.parametrize("shape,dtype,relu", [((2, 16, 8, 8), torch.float32, True), ((3, 7, 5, 3), torch.float32, False),
+                                               ((2, 24, 6, 6), torch.float16, True), ((8, 256, 64, 64), torch.float16, True),
+                                               ((4, 10, 3, 2), torch.float16, True)])
+def test_bn_act_dual_vs_oracle_and_torch(dev, shape, dtype, relu):
+    """relu(bn(x) + bn_r(residual)) in one launch against the CPU oracle and against the four device kernels
+    it replaces (MIOpen batch-norm twice, add, clamp): bit for bit; and through the ResNet bottleneck that uses it."""
+    from oracle import bnact as ob
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    c = shape[1]
+    bn, rbn = torch.nn.BatchNorm2d(c).eval(), torch.nn.BatchNorm2d(c, eps=1e-3).eval()
+    for m in (bn, rbn):
+        m.running_mean.copy_(torch.randn(c, generator=g))
+        m.running_var.copy_(torch.rand(c, generator=g) * 2 + 0.05)
+        m.weight.data.copy_(torch.rand(c, generator=g) + 0.5)
+        m.bias.data.copy_(torch.randn(c, generator=g))
+    x = (2.0 * torch.randn(*shape, generator=g)).to(dtype)
+    res = (2.0 * torch.randn(*shape, generator=g)).to(dtype)
+    want = ob.bn_act_dual(x, (bn.running_mean, bn.running_var, bn.weight.data, bn.bias.data, bn.eps), res,
+                          (rbn.running_mean, rbn.running_var, rbn.weight.data, rbn.bias.data, rbn.eps), relu=relu)
+    bn, rbn = bn.to(dev), rbn.to(dev)
+    with torch.no_grad():
+        got = ops.bn_act_dual(x.to(dev), bn, res.to(dev), rbn, relu=relu)
+        f = torch.nn.functional.batch_norm
+        there = (f(x.to(dev), bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps) +
+                 f(res.to(dev), rbn.running_mean, rbn.running_var, rbn.weight, rbn.bias, False, 0.0, rbn.eps))
+        if relu:
+            there = torch.relu(there)
+    assert got.dtype == dtype and torch.equal(got, there)
+    step = 4e-3 if dtype == torch.float16 else 4e-6
+    assert float((got.float().cpu() - want.float()).abs().max()) <= step * max(1.0, float(want.float().abs().max()))
+
+
+def test_bottleneck_with_projection_uses_one_tail_launch(dev):
+    """The first bottleneck of a ResNet stage: library forward (shortcut batch-norm fused into the tail) equals the
+    module-by-module torch forward of the same block, under autocast and in fp32."""
+    from spice_amd.nets import layers
+    from spice_amd.nets.resnet import Bottleneck
+    torch.manual_seed(3)
+    blk = Bottleneck(64, 32, stride=2, downsample=True).to(dev).eval()
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0.0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0.0, 0.2)
+    x = torch.randn(2, 64, 32, 32, device=dev)
+    for cast in (False, True):
+        with torch.autocast("cuda", dtype=torch.float16, enabled=cast), torch.no_grad():
+            mid = blk.conv3(blk.bn2(blk.conv2(blk.bn1(blk.conv1(x)))))
+            short = blk.downsample[0](x)
+            got = blk.bn3(mid, short, blk.downsample[1])
+            layers.set_library_forward(False)
+            try:
+                there = torch.relu(torch.nn.functional.batch_norm(
+                    mid, blk.bn3.running_mean, blk.bn3.running_var, blk.bn3.weight, blk.bn3.bias, False, 0.0, blk.bn3.eps) +
+                    blk.downsample[1](short))
+            finally:
+                layers.set_library_forward(True)
+            assert torch.equal(got, there.to(got.dtype)), cast
+            assert blk(x).shape == (2, 128, 16, 16)
 
 
 def test_bn_act_rejects_what_it_does_not_reproduce(dev):

@@ -381,6 +381,48 @@ Tensor conv1x1_f16(const Tensor &x, const Tensor &weight2d) {
     return out;
 }
 
+// conv1x1_f16 followed by the batch-norm tail (bn_act or bn_act_dual, written in place over the product): the two
+// launches of a 1x1-convolution + batch-norm pair of the models' forward behind ONE call from Python.
+Tensor conv1x1_bn_act(const Tensor &x, const Tensor &weight2d, const Tensor &mean, const Tensor &var,
+                      const Tensor &weight, const Tensor &bias, double eps, const c10::optional<Tensor> &residual,
+                      const c10::optional<Tensor> &r_mean, const c10::optional<Tensor> &r_var,
+                      const c10::optional<Tensor> &r_weight, const c10::optional<Tensor> &r_bias, double r_eps, bool relu) {
+    Tensor t = conv1x1_f16(x, weight2d);
+    TORCH_CHECK_VALUE(t.is_contiguous(), "conv1x1_bn_act: the product is not contiguous");
+    const int64_t c = t.size(1);
+    for (const Tensor *p : {&mean, &var, &weight, &bias})
+        TORCH_CHECK_TYPE(p->scalar_type() == at::kFloat && p->device() == t.device() && p->numel() == c && p->is_contiguous(),
+                         "conv1x1_bn_act: the four parameter vectors must be contiguous fp32 [", c, "] on ", t.device());
+    const void *res = nullptr;
+    if (residual.has_value()) {
+        TORCH_CHECK_VALUE(residual->sizes() == t.sizes(), "conv1x1_bn_act: residual must have the product's shape");
+        TORCH_CHECK_TYPE(residual->scalar_type() == t.scalar_type() && residual->device() == t.device() &&
+                             residual->is_contiguous(),
+                         "conv1x1_bn_act: residual must be contiguous fp16 on x's device");
+        res = residual->data_ptr();
+    }
+    c10::DeviceGuard guard(t.device());
+    int rc;
+    if (r_mean.has_value()) {
+        TORCH_CHECK_VALUE(res != nullptr && r_var.has_value() && r_weight.has_value() && r_bias.has_value(),
+                          "conv1x1_bn_act: a residual batch-norm needs the residual and all four of its vectors");
+        for (const Tensor *p : {&*r_mean, &*r_var, &*r_weight, &*r_bias})
+            TORCH_CHECK_TYPE(p->scalar_type() == at::kFloat && p->device() == t.device() && p->numel() == c &&
+                                 p->is_contiguous(),
+                             "conv1x1_bn_act: the residual's parameter vectors must be contiguous fp32 [", c, "]");
+        rc = spice_bn_act_dual(t.data_ptr(), res, t.data_ptr(), 1, mean.data_ptr<float>(), var.data_ptr<float>(),
+                               weight.data_ptr<float>(), bias.data_ptr<float>(), (float)eps, r_mean->data_ptr<float>(),
+                               r_var->data_ptr<float>(), r_weight->data_ptr<float>(), r_bias->data_ptr<float>(),
+                               (float)r_eps, t.size(0), c, t.size(2) * t.size(3), relu ? 1 : 0, current_stream(t));
+    } else {
+        rc = spice_bn_act(t.data_ptr(), res, t.data_ptr(), 1, mean.data_ptr<float>(), var.data_ptr<float>(),
+                          weight.data_ptr<float>(), bias.data_ptr<float>(), (float)eps, t.size(0), c, t.size(2) * t.size(3),
+                          relu ? 1 : 0, current_stream(t));
+    }
+    check_rc(rc, "spice_bn_act (behind conv1x1)");
+    return t;
+}
+
 int64_t abi_version() { return spice_abi_version(); }
 
 }  // namespace
@@ -411,4 +453,7 @@ TORCH_LIBRARY(spice, m) {
           "Tensor r_mean, Tensor r_var, Tensor r_weight, Tensor r_bias, float r_eps, bool relu) -> Tensor", &bn_act_dual);
     m.def("depthwise_conv3x3(Tensor x, Tensor weight, int dilation) -> Tensor", &depthwise_conv3x3);
     m.def("conv1x1_f16(Tensor x, Tensor weight2d) -> Tensor", &conv1x1_f16);
+    m.def("conv1x1_bn_act(Tensor x, Tensor weight2d, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, "
+          "Tensor? residual, Tensor? r_mean, Tensor? r_var, Tensor? r_weight, Tensor? r_bias, float r_eps, bool relu) "
+          "-> Tensor", &conv1x1_bn_act);
 }

@@ -9,7 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import layers
-from .layers import BatchNormAct2d, Conv1x1, DepthwiseConv3x3
+from .layers import BatchNormAct2d, Conv1x1, ConvBnAct, DepthwiseConv3x3, conv1x1_bn
 
 
 class SeparableConv2d(nn.Sequential):
@@ -71,7 +71,7 @@ class BilinearLike(nn.Upsample):
 
 
 def _conv_bn_relu(conv: nn.Module, ch: int) -> nn.Sequential:
-    return nn.Sequential(conv, BatchNormAct2d(ch, relu=True))
+    return ConvBnAct(conv, BatchNormAct2d(ch, relu=True))
 
 
 class ASPPPooling(nn.Module):
@@ -101,7 +101,8 @@ class ASPP(nn.Module):
                                      BatchNormAct2d(out_ch, relu=True), nn.Dropout(0.5))
 
     def forward(self, x):
-        return self.project(torch.cat([b(x) for b in self.convs], dim=1))
+        y = torch.cat([b(x) for b in self.convs], dim=1)
+        return self.project[2](conv1x1_bn(self.project[0], self.project[1], y))
 
 
 class DeepLabV3PlusDecoder(nn.Module):
@@ -122,7 +123,9 @@ class DeepLabV3PlusDecoder(nn.Module):
         self.out_channels = out_channels
 
     def forward(self, features: List[torch.Tensor]):
-        deep = self.up(self.aspp(features[-1]))
+        a = self.aspp   # ASPP -> separable 3x3 (depthwise, pointwise) -> batch-norm + ReLU
+        deep = self.up(conv1x1_bn(a[1][1], a[2], a[1][0](a[0](features[-1]))) if type(a[1][1]) is Conv1x1
+                       else a(features[-1]))
         high = self.block1(features[2])
         return self.block2(torch.cat([deep, high], dim=1))
 

@@ -130,3 +130,55 @@ class Conv1x1(nn.Conv2d):
             if x.is_contiguous():
                 return ops.conv1x1_f16(x, _fp16_matrix(self.weight))
         return super().forward(x)
+
+
+def _plain_inference_norm(bn: nn.BatchNorm2d) -> bool:
+    return (not bn.training and bn.track_running_stats and bn.affine and bn.weight.dtype == torch.float32
+            and bn.running_mean.dtype == torch.float32)
+
+
+def _hooked(m: nn.Module) -> bool:
+    return bool(m._forward_hooks or m._forward_pre_hooks)
+
+
+def conv1x1_bn(conv: Conv1x1, bn: BatchNormAct2d, x, residual=None, residual_norm: Optional[nn.BatchNorm2d] = None):
+    """bn(conv(x) [, residual [, residual_norm]]).  On the inference path of a HIP device, where `conv` is the
+    library's matrix product and `bn` the library's fused tail, the pair is ONE call of the extension (two launches,
+    the product normalised in place) instead of two module calls: the Python around a launch costs more than the
+    launch once the device work of a forward is a few milliseconds.  Modules carrying forward hooks, symbolic
+    tracing, training and every other situation take the modules one after the other."""
+    if (isinstance(x, torch.Tensor) and _LIBRARY_FORWARD and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4
+            and not torch.nn.modules.module._global_forward_hooks
+            and not (_hooked(conv) or _hooked(bn)) and conv.takes_matrix_path(x.dtype) and _plain_inference_norm(bn)
+            and (x.shape[2] * x.shape[3]) % 2 == 0):
+        ok = residual is None or (residual.dtype == torch.float16 and residual.is_contiguous()
+                                  and residual.shape[1] == conv.out_channels and residual.shape[2:] == x.shape[2:]
+                                  and residual.shape[0] == x.shape[0])
+        if residual_norm is not None:
+            ok = ok and residual is not None and _plain_inference_norm(residual_norm) and not _hooked(residual_norm) \
+                and residual_norm.num_features == bn.num_features
+        if ok:
+            if x.dtype != torch.float16:
+                x = x.to(torch.float16)   # what autocast does to a convolution's input
+            if x.is_contiguous():
+                return ops.conv1x1_bn_act(x, _fp16_matrix(conv.weight), bn, residual, residual_norm, bn.relu_after)
+    if residual is None:
+        return bn(conv(x))
+    if residual_norm is None:
+        return bn(conv(x), residual)
+    return bn(conv(x), residual, residual_norm)
+
+
+class ConvBnAct(nn.Sequential):
+    """Sequential(convolution, BatchNormAct2d); a 1x1 convolution and its batch-norm go through conv1x1_bn."""
+
+    def __init__(self, conv: nn.Module, bn: BatchNormAct2d):
+        super().__init__(conv, bn)
+
+    def forward(self, x):
+        conv = self[0]
+        if type(conv) is Conv1x1:
+            return conv1x1_bn(conv, self[1], x)
+        if isinstance(conv, nn.Sequential) and len(conv) == 2 and type(conv[1]) is Conv1x1:
+            return conv1x1_bn(conv[1], self[1], conv[0](x))   # separable: depthwise, then the pointwise pair
+        return self[1](conv(x))

@@ -6,7 +6,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .layers import BatchNormAct2d, Conv1x1
+from .layers import BatchNormAct2d, Conv1x1, conv1x1_bn
 
 
 class Bottleneck(nn.Module):
@@ -29,14 +29,14 @@ class Bottleneck(nn.Module):
                 nn.BatchNorm2d(planes * 4))
 
     def forward(self, x):
-        out = self.bn2(self.conv2(self.bn1(self.conv1(x))))
+        out = self.bn2(self.conv2(conv1x1_bn(self.conv1, self.bn1, x)))
         if self.downsample is None:
-            return self.bn3(self.conv3(out), x)
+            return conv1x1_bn(self.conv3, self.bn3, out, x)
         if not isinstance(x, torch.Tensor):
             # symbolic tracing (the channel-coupling analysis): the shortcut as the plain composition it is
             return self.bn3(self.conv3(out), self.downsample(x))
         # the shortcut's batch-norm rides along with bn3: relu(bn3(.) + bn_ds(conv_ds(x))) in one launch at inference
-        return self.bn3(self.conv3(out), self.downsample[0](x), self.downsample[1])
+        return conv1x1_bn(self.conv3, self.bn3, out, self.downsample[0](x), self.downsample[1])
 
 
 class ResNet50Encoder(nn.Module):

@@ -468,3 +468,21 @@ def conv1x1_f16(x: torch.Tensor, weight2d: torch.Tensor) -> torch.Tensor:
     if _conv1x1_fn is None:
         _conv1x1_fn = spice_ops().conv1x1_f16
     return _conv1x1_fn(x, weight2d)
+
+
+_conv1x1_bn_fn = None
+
+
+def conv1x1_bn_act(x: torch.Tensor, weight2d: torch.Tensor, bn: "torch.nn.BatchNorm2d",
+                   residual: Optional[torch.Tensor] = None, res_bn: Optional["torch.nn.BatchNorm2d"] = None,
+                   relu: bool = False) -> torch.Tensor:
+    """relu?(bn(weight2d @ x) [+ residual | + res_bn(residual)]): conv1x1_f16 then the fused batch-norm tail, both
+    launched from one call of the extension (the product is normalised in place)."""
+    global _conv1x1_bn_fn
+    if _conv1x1_bn_fn is None:
+        _conv1x1_bn_fn = spice_ops().conv1x1_bn_act
+    if res_bn is None:
+        return _conv1x1_bn_fn(x, weight2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, residual,
+                              None, None, None, None, 0.0, relu)
+    return _conv1x1_bn_fn(x, weight2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, residual,
+                          res_bn.running_mean, res_bn.running_var, res_bn.weight, res_bn.bias, res_bn.eps, relu)

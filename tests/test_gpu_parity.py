@@ -394,6 +394,56 @@ def test_selected_indices_from_device_scores_match_oracle(dev):
             np.testing.assert_array_equal(mine, theirs)
 
 
+def test_gather_staged_and_fallback_items_in_one_launch(dev):
+    """In-channel lists through the LDS-staged path and past its limits, mixed in ONE launch: several batches of
+    rows per item with a short last batch, identity rows with a column list, 3x3 kernels with few columns, a
+    source row too long for the stage, more kept columns than the column table holds, a row length that is not a
+    multiple of four, and a rows-only tensor.  Guard words around every destination stay untouched."""
+    rng = np.random.default_rng(17)
+    # (rows, cols, inner, keep_out?, kept columns)
+    tensors = [(37, 2048, 1, True, 1024),    # staged: 2 rows per batch, 25 kept rows -> 13 batches per item group
+               (50, 512, 1, False, 256),     # staged, identity rows
+               (24, 16, 9, True, 8),         # staged, 3x3, tiny rows: many rows per batch
+               (6, 1300, 4, True, 648),      # source row of 5200 words: too long for the stage -> element path
+               (3, 4800, 1, True, 2400),     # 2400 kept columns: more than the column table -> element path
+               (9, 64, 9, True, 31),         # row length 279: not a multiple of four -> element path
+               (128, 96, 1, True, None)]     # rows only
+    srcs, specs, idx_parts, refs = [], [], [], []
+    spos, dpos, ipos = 0, 0, 0
+    for rows, cols, inner, use_out, kept in tensors:
+        w = rng.standard_normal((rows, cols, inner)).astype(np.float32)
+        ko = np.sort(rng.choice(rows, max(1, rows * 2 // 3), replace=False)).astype(np.int64) if use_out else None
+        ki = np.sort(rng.choice(cols, kept, replace=False)).astype(np.int64) if kept else None
+        ref = w[ko] if ko is not None else w
+        ref = ref[:, ki] if ki is not None else ref
+        o_off = i_off = -1
+        if ko is not None:
+            o_off, ipos = ipos, ipos + len(ko)
+            idx_parts.append(ko)
+        if ki is not None:
+            i_off, ipos = ipos, ipos + len(ki)
+            idx_parts.append(ki)
+        specs.append(ops.GatherSpec(spos, dpos, o_off, i_off, ref.shape[0], ref.shape[1], cols, inner))
+        srcs.append((spos, w))
+        refs.append(ref)
+        spos += (w.size + 3) // 4 * 4
+        dpos += (ref.size + 3) // 4 * 4 + 4      # four guard words behind every destination
+    src = np.zeros(spos, dtype=np.float32)
+    for off, w in srcs:
+        src[off: off + w.size] = w.reshape(-1)
+    plan = ops.GatherPlan(specs, dev)
+    assert plan.plan_flags & 4                    # the launch carries LDS for its staged items
+    guard = np.float32(-3.5)
+    dst = torch.full((dpos,), float(guard), dtype=torch.float32, device=dev)
+    idx = torch.from_numpy(np.concatenate(idx_parts)).to(dev)
+    plan.run([torch.from_numpy(src).to(dev)], dst, idx)
+    out = dst.cpu().numpy()
+    for spec, ref in zip(specs, refs):
+        got = out[spec.dst_off: spec.dst_off + ref.size]
+        assert np.array_equal(got.view(np.uint32), ref.reshape(-1).view(np.uint32)), (spec.dst_rows, spec.dst_cols)
+        assert (out[spec.dst_off + ref.size: spec.dst_off + (ref.size + 3) // 4 * 4 + 4] == guard).all()
+
+
 def test_gather_unaligned_offsets_and_odd_rows(dev):
     """Layouts that rule out 16-byte moves: destinations and sources at offsets that are not a
     multiple of four words, rows of odd length, one-row and one-column tensors, identity row

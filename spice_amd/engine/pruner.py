@@ -283,15 +283,57 @@ class MagnitudePruner:
         else:
             self._step_local()
 
+    def _n_to_prune_local(self, g: ChannelGroup) -> int:
+        ratio = min(self.target_ratio(g), self.max_pruning_ratio)
+        n_pruned = g.size - int(self.init_channels[g.root] * (1 - ratio))
+        if self.round_to:
+            n_pruned -= n_pruned % self.round_to
+        return n_pruned
+
+    @staticmethod
+    def _independent_levels(groups: Sequence[ChannelGroup]) -> List[List[ChannelGroup]]:
+        """Groups in module order, split into levels: a group's level is one more than the highest level of
+        an EARLIER group that shares a layer with it.  A group's importance reads only its own members'
+        tensors, so slicing the groups of one level together (after all lower levels) gives exactly what
+        slicing group after group in module order gives."""
+        last: Dict[int, int] = {}
+        levels: List[List[ChannelGroup]] = []
+        for g in groups:
+            mods = {id(m.module) for m in g.members}
+            lvl = 1 + max((last.get(k, -1) for k in mods), default=-1)
+            for k in mods:
+                last[k] = lvl
+            while len(levels) <= lvl:
+                levels.append([])
+            levels[lvl].append(g)
+        return levels
+
     def _step_local(self) -> None:
-        for g in self.prunable_groups():
+        groups = self.prunable_groups()
+        if hasattr(self.importance, "batch"):
+            # one importance pass (two launches, one device-to-host copy) and one gather launch per LEVEL of
+            # mutually independent groups instead of per group: the same channels, fewer host round trips
+            for level in self._independent_levels(groups):
+                decisions = []
+                for g, imp in zip(level, self.importance.batch(level)):
+                    if imp is None:
+                        continue
+                    imp = np.asarray(imp, dtype=np.float32)
+                    if imp.size != g.size:
+                        raise RuntimeError(f"importance returned {imp.size} scores for a group of {g.size} channels")
+                    n_pruned = self._n_to_prune_local(g)
+                    if n_pruned <= 0 or n_pruned >= g.size:
+                        continue
+                    order = np.argsort(imp, kind="stable")  # ascending score, then ascending index
+                    decisions.append((g, np.sort(order[:n_pruned])))
+                if decisions:
+                    self.last_step_bytes += apply_pruning(decisions)
+            return
+        for g in groups:   # importance plug-ins without a batch form: group after group
             imp = self._importance_of(g)
             if imp is None:
                 continue
-            ratio = min(self.target_ratio(g), self.max_pruning_ratio)
-            n_pruned = g.size - int(self.init_channels[g.root] * (1 - ratio))
-            if self.round_to:
-                n_pruned -= n_pruned % self.round_to
+            n_pruned = self._n_to_prune_local(g)
             if n_pruned <= 0 or n_pruned >= g.size:
                 continue
             order = np.argsort(imp, kind="stable")  # ascending score, then ascending index

@@ -8,15 +8,22 @@ from spice_amd.pruning.models import ModelFactory
 from spice_amd.pruning.model_configs import MODEL_CONFIGS
 dev = torch.device("cuda:0")
 for name in MODEL_CONFIGS:
-    for mode in (False, True):
+    for mode in (False, "serial", True):
         torch.manual_seed(0)
         cfg = PruningConfig(model_name=name, use_wandb=False, output_dir="/tmp/unused_spice")
         model = ModelFactory.create_model(cfg).to(dev).eval()
         ignored = ModelFactory.get_ignored_layers(model, cfg)
         x = torch.randn(1, 3, 576, 576, device=dev)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        pr = engine.MagnitudePruner(model, example_inputs=x, importance=engine.MagnitudeImportance(p=2), pruning_ratio=0.5,
-                                    iterative_steps=3, ignored_layers=ignored, global_pruning=mode)
+        imp = engine.MagnitudeImportance(p=2)
+        if mode == "serial":  # a plug-in importance without batch(): the group-after-group local path
+            inner = imp
+            class OneByOne(engine.Importance):
+                def __call__(self, group):
+                    return inner(group)
+            imp = OneByOne()
+        pr = engine.MagnitudePruner(model, example_inputs=x, importance=imp, pruning_ratio=0.5,
+                                    iterative_steps=3, ignored_layers=ignored, global_pruning=(mode is True))
         torch.cuda.synchronize(); t1 = time.perf_counter()
         steps = []
         for s in range(3):

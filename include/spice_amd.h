@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPICE_ABI_VERSION 3
+#define SPICE_ABI_VERSION 4
 
 #define SPICE_OK 0
 #define SPICE_ERR_ARG 10001         /* null pointer, negative size, misaligned base */
@@ -346,6 +346,23 @@ int spice_depthwise_conv3x3_dilated(const void *x, const void *weight, int32_t w
  * ------------------------------------------------------------------------- */
 int spice_conv1x1_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int64_t hw,
                       int64_t cout, void *stream);
+
+/* The same product with the batch-norm that follows it in those models and the tail of a residual block
+ * applied before the result leaves the compute unit (pruning/models.py:35-39's networks: conv1/bn1 and
+ * conv3/bn3 of every bottleneck, the ASPP branches and projections):
+ *   y = relu?( bn(weight @ x) [+ residual | + bn_r(residual)] )
+ * ONE launch of a hand-written matrix-core kernel (v_mfma_f32_32x32x16_f16) instead of the product and a
+ * batch-norm pass over it.  The product is rounded to fp16 where spice_conv1x1_f16 would have stored it and
+ * the tail is spice_bn_act's / spice_bn_act_dual's arithmetic, so the values are those of the two calls up to
+ * the order of the fp32 sums.  mean == NULL: the plain product (no tail; residual must be NULL).
+ * residual is [n, Cout, HW] fp16 or NULL; the r_* vectors are all NULL or all set (then residual is required).
+ * HW must be a multiple of 8 and x, y, residual 16-byte aligned, else SPICE_ERR_UNSUPPORTED (callers then use
+ * the two calls above).  Holds no state and uses no scratch memory. */
+int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int64_t hw,
+                             int64_t cout, const float *mean, const float *var, const float *bn_weight,
+                             const float *bn_bias, float eps, const void *residual, const float *r_mean,
+                             const float *r_var, const float *r_weight, const float *r_bias, float r_eps,
+                             int32_t relu, void *stream);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libspice_amd.so")
 TORCH_LIB_PATH = os.path.join(_HERE, "lib", "libspice_torch.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 ERR_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_BLAS, ERR_STATIC_LIMIT = 10001, 10002, 10003, 10004, 10005
 IMP_L1, IMP_L2, IMP_TAYLOR = 0, 1, 2
 
@@ -100,6 +100,9 @@ SIGNATURES = {
     "spice_depthwise_conv3x3_dilated": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int64, c_int32,
                                                   c_int32, c_int32, c_void_p]),
     "spice_conv1x1_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    "spice_conv1x1_bn_act_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_void_p]),
     "spice_upsample_bilinear": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_int32,
                                           c_int32, c_int32, c_int32, c_float, c_float, c_void_p]),
 }

@@ -5,14 +5,10 @@
 // pruning/models.py:35-39 (MIOpen's batch-norm, torch's add, torch's clamp) by one that reads x (and the
 // residual) once and writes y once.
 //
-// The arithmetic repeats what those three kernels do, value for value:
-//   bn:   inv = v_rsq_f32(|var + eps|);  t = (x - mean) * inv;  o = fma(weight, t, bias)   (fp32)
-//         rounded to the tensor's dtype (for fp16: to nearest even, as a separate step)
-//   add:  the two rounded operands added in fp32, rounded again
-//   relu: max(v, 0), NaN kept
+// The arithmetic (bn_math.h) repeats what those three kernels do, value for value.
 // For fp16 tensors this is what MIOpen's kernel computes when H*W is even; the host refuses odd
 // plane sizes for fp16 (MIOpen's code for those fuses the rounding into the multiply-add).
-#include "common.h"
+#include "bn_math.h"
 
 #include <hip/hip_fp16.h>
 
@@ -34,37 +30,12 @@ struct BnArgs {
     int relu;
 };
 
-struct BnChannel {
-    float mean, inv, weight, bias;
-};
-
 __device__ __forceinline__ BnChannel bn_channel(const BnArgs &a, unsigned ch) {
-    BnChannel p;
-    p.mean = a.mean[ch];
-    p.inv = __builtin_amdgcn_rsqf(fabsf(a.var[ch] + a.eps));
-    p.weight = a.weight[ch];
-    p.bias = a.bias[ch];
-    return p;
+    return bn_channel_of(a.mean, a.var, a.weight, a.bias, a.eps, ch);
 }
 
 __device__ __forceinline__ BnChannel bn_channel_res(const BnArgs &a, unsigned ch) {
-    BnChannel p;
-    p.mean = a.r_mean[ch];
-    p.inv = __builtin_amdgcn_rsqf(fabsf(a.r_var[ch] + a.r_eps));
-    p.weight = a.r_weight[ch];
-    p.bias = a.r_bias[ch];
-    return p;
-}
-
-// round to the storage type and come back, so that later steps see what a separate kernel would read
-template <typename T>
-__device__ __forceinline__ float round_trip(float v);
-template <>
-__device__ __forceinline__ float round_trip<float>(float v) { return v; }
-template <>
-__device__ __forceinline__ float round_trip<_Float16>(float v) {
-    asm volatile("" : "+v"(v));   // the conversion stays a step of its own (no mixed-precision multiply-add)
-    return static_cast<float>(static_cast<_Float16>(v));
+    return bn_channel_of(a.r_mean, a.r_var, a.r_weight, a.r_bias, a.r_eps, ch);
 }
 
 template <typename T, int VEC>
@@ -91,20 +62,8 @@ __device__ __forceinline__ void bn_vector(const BnArgs &a, typename Pack<T, VEC>
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         const bool next = rem + e >= a.hw;
-        const float m = next ? p1.mean : p0.mean, inv = next ? p1.inv : p0.inv;
-        const float w = next ? p1.weight : p0.weight, b = next ? p1.bias : p0.bias;
-        const float t = (static_cast<float>(xv[e]) - m) * inv;
-        float v = round_trip<T>(__builtin_fmaf(w, t, b));
-        if constexpr (HAS_RES) {
-            float r = static_cast<float>(rv[e]);
-            if constexpr (RES_BN) {   // the shortcut's batch-norm, stored in T by its own kernel before the add
-                const float rm = next ? q1.mean : q0.mean, rinv = next ? q1.inv : q0.inv;
-                const float rw = next ? q1.weight : q0.weight, rb = next ? q1.bias : q0.bias;
-                r = round_trip<T>(__builtin_fmaf(rw, (r - rm) * rinv, rb));
-            }
-            v = round_trip<T>(v + r);
-        }
-        if (a.relu) v = v != v ? v : fmaxf(v, 0.0f);
+        const float v = bn_tail<T, HAS_RES, RES_BN>(static_cast<float>(xv[e]), static_cast<float>(rv[e]), next ? p1 : p0,
+                                                    next ? q1 : q0, a.relu);
         o[e] = static_cast<T>(v);
     }
     *out = o;

@@ -1,0 +1,289 @@
+// 1x1 stride-1 convolution of fp16 NCHW activations with the inference batch-norm and the element-wise
+// tail of a residual block applied to the product before it leaves the compute unit:
+//   Y[n][Cout, HW] = relu?( bn( W[Cout, Cin] @ X[n][Cin, HW] ) [+ R | + bn_r(R)] )
+// one launch instead of a matrix product and a batch-norm pass over its result (the pairs of
+// pruning/models.py:35-39's networks: every bottleneck's conv1/bn1 and conv3/bn3, the ASPP branches and
+// projections).  The product is rounded to fp16 where the separate product would have stored it and the
+// tail is the arithmetic of bn_math.h, so the values are those of the two-launch route up to the order of
+// the fp32 sums.  mean == nullptr leaves the tail out (the plain product).
+//
+// These products are mostly bound by memory (Cin, Cout <= 2048 against 8K-128K pixels), so the kernel is
+// laid out for traffic first: X is read once per 128 output channels in 16-byte pieces, the product never
+// goes to memory in fp32 or un-normalised, the residual and Y move in 16-byte pieces.
+//
+// Workgroup: 256 lanes = 4 waves on a 128 (channels) x 64 (pixels of one image) tile, K in steps of 64.
+//   LDS   A[128][72]  weights, K contiguous (144-byte rows: a ds_read_b128 of 16 consecutive rows covers all 64 banks once)
+//         B[64][64]   activations as they lie in memory, pixels contiguous, 16-byte pieces XOR-swizzled by the row
+//   wave w owns channels 32 w .. +31 and all 64 pixels: two v_mfma_f32_32x32x16_f16 per 16 of K, with the PIXELS as
+//   the rows of the product (so that a lane ends up holding four consecutive pixels of one channel):
+//         A operand: lane l holds X^T[pixel l & 31][k = 8 (l >> 5) + 0..7]      two ds_read_b64_tr_b16, which hand each
+//                    lane a COLUMN of a 4 x 16 block of the pixel-contiguous image
+//         B operand: lane l holds W^T[k = 8 (l >> 5) + 0..7][channel l & 31]    one ds_read_b128 of a row of A
+//         result:    lane l holds channel l & 31, pixels (r & 3) + 8 (r >> 2) + 4 (l >> 5) in register r
+//   Epilogue: accumulators -> fp16 -> LDS C[128][72] (8-byte writes) -> row-major 16-byte pieces -> tail -> global.
+//   The residual's pieces are requested before the products start, so they have arrived when the tail needs them.
+#include "bn_math.h"
+
+namespace spice {
+
+constexpr int kMmThreads = 256;
+constexpr int kMmBM = 128, kMmBN = 64, kMmBK = 64;
+constexpr int kMmAPitch = 72;    // halfs
+constexpr int kMmBPitch = 64;    // halfs (swizzled, no padding)
+constexpr int kMmCPitch = 72;    // halfs
+constexpr int kMmLdsHalfs = kMmBM * kMmAPitch + kMmBK * kMmBPitch;   // 26,624 bytes; the C image reuses the front
+static_assert(kMmBM * kMmCPitch <= kMmLdsHalfs, "the C image fits in the A and B images' storage");
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef short short8_t __attribute__((ext_vector_type(8)));
+typedef short short4_t __attribute__((__vector_size__(4 * sizeof(short))));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) short4_t *lds_short4_ptr;
+
+struct MmArgs {
+    const _Float16 *x;      // [n][K][hw]
+    const _Float16 *w;      // [M][K]
+    _Float16 *y;            // [n][M][hw]
+    const _Float16 *res;    // [n][M][hw] or null
+    const float *mean, *var, *weight, *bias;           // null mean: no batch-norm, no tail
+    const float *r_mean, *r_var, *r_weight, *r_bias;   // batch-norm of the residual, or null
+    float eps, r_eps;
+    int M, K, hw;
+    int tiles_m, tiles_n;   // per image
+    unsigned total_tiles;
+    int relu;
+};
+
+// Workgroups are dealt to the eight XCDs round-robin; consecutive tiles (same pixels, next 128 channels) share
+// their X tile, so a run of consecutive tiles goes to ONE XCD's L2 when the tile count allows.
+__device__ __forceinline__ unsigned mm_tile_of_block(unsigned id, unsigned total) {
+    if (total % 8u != 0) return id;
+    return (id & 7u) * (total >> 3) + (id >> 3);
+}
+
+// Offset (halfs) of 16-byte piece `piece` (0..7) of row `k` of the B image.  Rows are 128 bytes, so rows k and
+// k + 2 start on the same bank; the transposed read of a half-wave takes 4 rows x 2 pairs of pieces, which land
+// on eight different 32-byte bank ranges once the pieces of rows with bit 1 set are exchanged pairwise.
+__device__ __forceinline__ int mm_b_offset(int k, int piece) { return k * kMmBPitch + ((piece ^ ((k & 2) << 1)) << 3); }
+
+template <bool A_VEC>
+__global__ __launch_bounds__(kMmThreads, 4) void conv1x1_bn_act_mfma_kernel(MmArgs a) {
+    __shared__ __attribute__((aligned(16))) _Float16 lds[kMmLdsHalfs];
+    _Float16 *As = lds;
+    _Float16 *Bs = lds + kMmBM * kMmAPitch;
+
+    const unsigned tile = mm_tile_of_block(blockIdx.x, a.total_tiles);
+    const int mt = static_cast<int>(tile % static_cast<unsigned>(a.tiles_m));
+    const unsigned rest = tile / static_cast<unsigned>(a.tiles_m);
+    const int nt = static_cast<int>(rest % static_cast<unsigned>(a.tiles_n));
+    const size_t img = rest / static_cast<unsigned>(a.tiles_n);
+    const int m0 = mt * kMmBM, n0 = nt * kMmBN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+
+    // the row-major pass of the epilogue: lane takes 8 consecutive pixels of one channel, 4 such pieces
+    const int e_pc = (tid & 7) * 8, e_row = tid >> 3;   // rows e_row + 32 i
+    const int e_p = n0 + e_pc;
+    const bool has_bn = a.mean != nullptr, has_res = a.res != nullptr, res_bn = a.r_mean != nullptr;
+    uint4 rres[4];
+    if (has_res) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + e_row + 32 * i;
+            rres[i] = make_uint4(0, 0, 0, 0);
+            if (m < a.M && e_p < a.hw)
+                rres[i] = *reinterpret_cast<const uint4 *>(a.res + (img * a.M + m) * static_cast<size_t>(a.hw) + e_p);
+        }
+    }
+
+    const _Float16 *xi = a.x + img * static_cast<size_t>(a.K) * a.hw;
+
+    // global -> register staging per K step: four 16-byte pieces of A and two of B per lane
+    uint4 ra[4], rb[2];
+    auto load_step = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + kMmThreads * i;
+            const int m = m0 + (c >> 3), k = k0 + (c & 7) * 8;
+            ra[i] = make_uint4(0, 0, 0, 0);
+            if (m < a.M && k < a.K) {
+                const _Float16 *src = a.w + static_cast<size_t>(m) * a.K + k;
+                if constexpr (A_VEC) {
+                    ra[i] = *reinterpret_cast<const uint4 *>(src);
+                } else {   // rows of W that do not start on 16 bytes, or a K that ends inside the piece
+                    half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (k + e < a.K) v[e] = src[e];
+                    ra[i] = __builtin_bit_cast(uint4, v);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + kMmThreads * i;
+            const int kk = k0 + (c >> 3), p = n0 + (c & 7) * 8;
+            rb[i] = make_uint4(0, 0, 0, 0);
+            if (kk < a.K && p < a.hw)   // hw is a multiple of 8: a piece is inside the row or outside it
+                rb[i] = *reinterpret_cast<const uint4 *>(xi + static_cast<size_t>(kk) * a.hw + p);
+        }
+    };
+    auto store_step = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + kMmThreads * i;
+            *reinterpret_cast<uint4 *>(As + (c >> 3) * kMmAPitch + (c & 7) * 8) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + kMmThreads * i;
+            *reinterpret_cast<uint4 *>(Bs + mm_b_offset(c >> 3, c & 7)) = rb[i];
+        }
+    };
+
+    float16_t acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // operand addresses inside the LDS images (halfs), without the K-step part
+    const int h = lane >> 5;
+    const int w_off = (32 * wave + (lane & 31)) * kMmAPitch + 8 * h;   // + 16 s
+    // transposed read: lane 4q + p of a 16-lane group supplies row q, pixels 4p .. 4p+3 of the group's 16 pixels
+    const int g_b = (lane >> 4) & 1, g_q = (lane & 15) >> 2, g_p = lane & 3;
+    const int x_row = 8 * h + g_q;                                      // + 16 s (+ 4 for the second read)
+    const bool wave_has_rows = m0 + 32 * wave < a.M;   // uniform per wave
+
+    load_step(0);
+    for (int k0 = 0; k0 < a.K; k0 += kMmBK) {
+        __syncthreads();   // every wave has read the previous step's images
+        store_step();
+        __syncthreads();
+        if (k0 + kMmBK < a.K) load_step(k0 + kMmBK);   // in flight during the products below
+        if (wave_has_rows) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const half8_t fw = *reinterpret_cast<const half8_t *>(As + w_off + 16 * s);
+                half8_t fx[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    // pixels 32 t + 16 g_b + 4 g_p ..: piece 4 t + 2 g_b + (g_p >> 1), second half of it for odd g_p
+                    const int piece = 4 * t + 2 * g_b + (g_p >> 1), within = 4 * (g_p & 1);
+                    const int k_lo = 16 * s + x_row, k_hi = k_lo + 4;
+                    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(Bs + mm_b_offset(k_lo, piece) + within));
+                    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(Bs + mm_b_offset(k_hi, piece) + within));
+                    const short8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    fx[t] = __builtin_bit_cast(half8_t, both);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fx[t], fw, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // accumulators -> fp16 (the rounding of a stored product) -> C image [channel][pixel], four pixels per write
+    __syncthreads();
+    _Float16 *Cs = lds;
+    if (wave_has_rows) {
+        const int row = 32 * wave + (lane & 31);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                half4_t v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = static_cast<_Float16>(acc[t][4 * rq + e]);
+                *reinterpret_cast<half4_t *>(Cs + row * kMmCPitch + 32 * t + 8 * rq + 4 * h) = v;
+            }
+    }
+    __syncthreads();
+
+    if (e_p >= a.hw) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = e_row + 32 * i;
+        const int m = m0 + row;
+        if (m >= a.M) break;   // rows ascend with i
+        half8_t v = *reinterpret_cast<const half8_t *>(Cs + row * kMmCPitch + e_pc);
+        const size_t at = (img * a.M + m) * static_cast<size_t>(a.hw) + e_p;
+        if (has_bn) {
+            const BnChannel pch = bn_channel_of(a.mean, a.var, a.weight, a.bias, a.eps, m);
+            if (has_res) {
+                const half8_t r = __builtin_bit_cast(half8_t, rres[i]);
+                if (res_bn) {
+                    const BnChannel qch = bn_channel_of(a.r_mean, a.r_var, a.r_weight, a.r_bias, a.r_eps, m);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        v[e] = static_cast<_Float16>(bn_tail<_Float16, true, true>(static_cast<float>(v[e]),
+                                                                                   static_cast<float>(r[e]), pch, qch, a.relu));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        v[e] = static_cast<_Float16>(bn_tail<_Float16, true, false>(static_cast<float>(v[e]),
+                                                                                    static_cast<float>(r[e]), pch, pch, a.relu));
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    v[e] = static_cast<_Float16>(bn_tail<_Float16, false, false>(static_cast<float>(v[e]), 0.0f, pch, pch, a.relu));
+            }
+        }
+        *reinterpret_cast<half8_t *>(a.y + at) = v;
+    }
+}
+
+}  // namespace spice
+
+extern "C" int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int64_t hw,
+                                        int64_t cout, const float *mean, const float *var, const float *bn_weight,
+                                        const float *bn_bias, float eps, const void *residual, const float *r_mean,
+                                        const float *r_var, const float *r_weight, const float *r_bias, float r_eps,
+                                        int32_t relu, void *stream) {
+    using namespace spice;
+    if (n < 0 || cin <= 0 || hw < 0 || cout <= 0) return SPICE_ERR_ARG;
+    if (n == 0 || hw == 0) return SPICE_OK;
+    if (x == nullptr || weight == nullptr || y == nullptr) return SPICE_ERR_ARG;
+    if (mean != nullptr && (var == nullptr || bn_weight == nullptr || bn_bias == nullptr)) return SPICE_ERR_ARG;
+    if (mean == nullptr && (residual != nullptr || r_mean != nullptr)) return SPICE_ERR_ARG;
+    if (r_mean != nullptr && (residual == nullptr || r_var == nullptr || r_weight == nullptr || r_bias == nullptr))
+        return SPICE_ERR_ARG;
+    // 16-byte pieces of whole rows of X, R and Y: the plane size must be a multiple of 8 halfs
+    if ((hw & 7) != 0 || !aligned16(x) || !aligned16(y) || (residual != nullptr && !aligned16(residual)))
+        return SPICE_ERR_UNSUPPORTED;
+    if (cin > (1 << 20) || cout > (1 << 20) || hw > (1 << 28)) return SPICE_ERR_UNSUPPORTED;
+    const int64_t tiles_m = ceil_div(cout, kMmBM), tiles_n = ceil_div(hw, kMmBN);
+    if (tiles_m * tiles_n > INT32_MAX / n) return SPICE_ERR_UNSUPPORTED;
+    MmArgs a;
+    a.x = static_cast<const _Float16 *>(x);
+    a.w = static_cast<const _Float16 *>(weight);
+    a.y = static_cast<_Float16 *>(y);
+    a.res = static_cast<const _Float16 *>(residual);
+    a.mean = mean;
+    a.var = var;
+    a.weight = bn_weight;
+    a.bias = bn_bias;
+    a.r_mean = r_mean;
+    a.r_var = r_var;
+    a.r_weight = r_weight;
+    a.r_bias = r_bias;
+    a.eps = eps;
+    a.r_eps = r_eps;
+    a.M = static_cast<int>(cout);
+    a.K = static_cast<int>(cin);
+    a.hw = static_cast<int>(hw);
+    a.tiles_m = static_cast<int>(tiles_m);
+    a.tiles_n = static_cast<int>(tiles_n);
+    a.total_tiles = static_cast<unsigned>(tiles_m * tiles_n * n);
+    a.relu = relu ? 1 : 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(a.total_tiles), block(kMmThreads);
+    if ((cin & 7) == 0 && aligned16(weight))
+        hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<true>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<false>), grid, block, 0, st, a);
+    SPICE_LAUNCH_CHECK();
+    return SPICE_OK;
+}

@@ -18,6 +18,8 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <limits>
 #include <tuple>
@@ -381,39 +383,79 @@ Tensor conv1x1_f16(const Tensor &x, const Tensor &weight2d) {
     return out;
 }
 
-// conv1x1_f16 followed by the batch-norm tail (bn_act or bn_act_dual, written in place over the product): the two
-// launches of a 1x1-convolution + batch-norm pair of the models' forward behind ONE call from Python.
+// relu?( bn(weight2d @ x) [+ residual | + bn_r(residual)] ) behind ONE call from Python.  First choice: the
+// matrix-core kernel that applies the tail to the product before it is stored (one launch).  Where that kernel
+// does not take the shapes (SPICE_ERR_UNSUPPORTED) or SPICE_CONV1X1_FUSED=0 is set: conv1x1_f16 followed by the
+// batch-norm tail (bn_act or bn_act_dual) written in place over the product (two launches).  `route` 1 / 2 asks
+// for the one-launch / two-launch route explicitly (1 raises where the kernel does not take the shapes).
+static bool fused_conv1x1_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("SPICE_CONV1X1_FUSED");
+        return e == nullptr || atoi(e) != 0;
+    }();
+    return on;
+}
+
 Tensor conv1x1_bn_act(const Tensor &x, const Tensor &weight2d, const Tensor &mean, const Tensor &var,
                       const Tensor &weight, const Tensor &bias, double eps, const c10::optional<Tensor> &residual,
                       const c10::optional<Tensor> &r_mean, const c10::optional<Tensor> &r_var,
-                      const c10::optional<Tensor> &r_weight, const c10::optional<Tensor> &r_bias, double r_eps, bool relu) {
-    Tensor t = conv1x1_f16(x, weight2d);
-    TORCH_CHECK_VALUE(t.is_contiguous(), "conv1x1_bn_act: the product is not contiguous");
-    const int64_t c = t.size(1);
+                      const c10::optional<Tensor> &r_weight, const c10::optional<Tensor> &r_bias, double r_eps, bool relu,
+                      int64_t route) {
+    TORCH_CHECK_VALUE(route >= 0 && route <= 2, "conv1x1_bn_act: route must be 0 (choose), 1 (one launch) or 2 (two launches)");
+    TORCH_CHECK_TYPE(x.scalar_type() == at::kHalf && weight2d.scalar_type() == at::kHalf,
+                     "conv1x1_bn_act: x and weight must be fp16");
+    TORCH_CHECK(x.is_cuda(), "x is on ", x.device(),
+                "; the MI355X path has no CPU implementation (move the tensor to a HIP device)");
+    TORCH_CHECK(weight2d.device() == x.device(), "conv1x1_bn_act: weight must be on x's device");
+    TORCH_CHECK_VALUE(x.dim() == 4 && weight2d.dim() == 2 && weight2d.size(1) == x.size(1) && x.is_contiguous() &&
+                          weight2d.is_contiguous(),
+                      "conv1x1_bn_act: x must be contiguous [N,Cin,H,W] and weight contiguous [Cout,Cin]");
+    const int64_t n = x.size(0), cin = x.size(1), h = x.size(2), w = x.size(3), c = weight2d.size(0);
     for (const Tensor *p : {&mean, &var, &weight, &bias})
-        TORCH_CHECK_TYPE(p->scalar_type() == at::kFloat && p->device() == t.device() && p->numel() == c && p->is_contiguous(),
-                         "conv1x1_bn_act: the four parameter vectors must be contiguous fp32 [", c, "] on ", t.device());
+        TORCH_CHECK_TYPE(p->scalar_type() == at::kFloat && p->device() == x.device() && p->numel() == c && p->is_contiguous(),
+                         "conv1x1_bn_act: the four parameter vectors must be contiguous fp32 [", c, "] on ", x.device());
     const void *res = nullptr;
     if (residual.has_value()) {
-        TORCH_CHECK_VALUE(residual->sizes() == t.sizes(), "conv1x1_bn_act: residual must have the product's shape");
-        TORCH_CHECK_TYPE(residual->scalar_type() == t.scalar_type() && residual->device() == t.device() &&
+        TORCH_CHECK_VALUE(residual->dim() == 4 && residual->size(0) == n && residual->size(1) == c &&
+                              residual->size(2) == h && residual->size(3) == w,
+                          "conv1x1_bn_act: residual must have the product's shape");
+        TORCH_CHECK_TYPE(residual->scalar_type() == at::kHalf && residual->device() == x.device() &&
                              residual->is_contiguous(),
                          "conv1x1_bn_act: residual must be contiguous fp16 on x's device");
         res = residual->data_ptr();
     }
-    c10::DeviceGuard guard(t.device());
-    int rc;
+    const float *rm = nullptr, *rv = nullptr, *rw = nullptr, *rb = nullptr;
     if (r_mean.has_value()) {
         TORCH_CHECK_VALUE(res != nullptr && r_var.has_value() && r_weight.has_value() && r_bias.has_value(),
                           "conv1x1_bn_act: a residual batch-norm needs the residual and all four of its vectors");
         for (const Tensor *p : {&*r_mean, &*r_var, &*r_weight, &*r_bias})
-            TORCH_CHECK_TYPE(p->scalar_type() == at::kFloat && p->device() == t.device() && p->numel() == c &&
+            TORCH_CHECK_TYPE(p->scalar_type() == at::kFloat && p->device() == x.device() && p->numel() == c &&
                                  p->is_contiguous(),
                              "conv1x1_bn_act: the residual's parameter vectors must be contiguous fp32 [", c, "]");
+        rm = r_mean->data_ptr<float>();
+        rv = r_var->data_ptr<float>();
+        rw = r_weight->data_ptr<float>();
+        rb = r_bias->data_ptr<float>();
+    }
+    c10::DeviceGuard guard(x.device());
+    if (route == 1 || (route == 0 && fused_conv1x1_enabled())) {
+        Tensor out = at::empty({n, c, h, w}, x.options());
+        const int rc = spice_conv1x1_bn_act_f16(x.data_ptr(), weight2d.data_ptr(), out.data_ptr(), n, cin, h * w, c,
+                                                mean.data_ptr<float>(), var.data_ptr<float>(), weight.data_ptr<float>(),
+                                                bias.data_ptr<float>(), (float)eps, res, rm, rv, rw, rb, (float)r_eps,
+                                                relu ? 1 : 0, current_stream(x));
+        if (rc != SPICE_ERR_UNSUPPORTED || route == 1) {
+            check_rc(rc, "spice_conv1x1_bn_act_f16");
+            return out;
+        }
+    }
+    Tensor t = conv1x1_f16(x, weight2d);
+    TORCH_CHECK_VALUE(t.is_contiguous(), "conv1x1_bn_act: the product is not contiguous");
+    int rc;
+    if (rm != nullptr) {
         rc = spice_bn_act_dual(t.data_ptr(), res, t.data_ptr(), 1, mean.data_ptr<float>(), var.data_ptr<float>(),
-                               weight.data_ptr<float>(), bias.data_ptr<float>(), (float)eps, r_mean->data_ptr<float>(),
-                               r_var->data_ptr<float>(), r_weight->data_ptr<float>(), r_bias->data_ptr<float>(),
-                               (float)r_eps, t.size(0), c, t.size(2) * t.size(3), relu ? 1 : 0, current_stream(t));
+                               weight.data_ptr<float>(), bias.data_ptr<float>(), (float)eps, rm, rv, rw, rb, (float)r_eps,
+                               t.size(0), c, t.size(2) * t.size(3), relu ? 1 : 0, current_stream(t));
     } else {
         rc = spice_bn_act(t.data_ptr(), res, t.data_ptr(), 1, mean.data_ptr<float>(), var.data_ptr<float>(),
                           weight.data_ptr<float>(), bias.data_ptr<float>(), (float)eps, t.size(0), c, t.size(2) * t.size(3),
@@ -454,6 +496,6 @@ TORCH_LIBRARY(spice, m) {
     m.def("depthwise_conv3x3(Tensor x, Tensor weight, int dilation) -> Tensor", &depthwise_conv3x3);
     m.def("conv1x1_f16(Tensor x, Tensor weight2d) -> Tensor", &conv1x1_f16);
     m.def("conv1x1_bn_act(Tensor x, Tensor weight2d, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, "
-          "Tensor? residual, Tensor? r_mean, Tensor? r_var, Tensor? r_weight, Tensor? r_bias, float r_eps, bool relu) "
-          "-> Tensor", &conv1x1_bn_act);
+          "Tensor? residual, Tensor? r_mean, Tensor? r_var, Tensor? r_weight, Tensor? r_bias, float r_eps, bool relu, "
+          "int route) -> Tensor", &conv1x1_bn_act);
 }

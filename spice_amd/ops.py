@@ -475,14 +475,16 @@ _conv1x1_bn_fn = None
 
 def conv1x1_bn_act(x: torch.Tensor, weight2d: torch.Tensor, bn: "torch.nn.BatchNorm2d",
                    residual: Optional[torch.Tensor] = None, res_bn: Optional["torch.nn.BatchNorm2d"] = None,
-                   relu: bool = False) -> torch.Tensor:
-    """relu?(bn(weight2d @ x) [+ residual | + res_bn(residual)]): conv1x1_f16 then the fused batch-norm tail, both
-    launched from one call of the extension (the product is normalised in place)."""
+                   relu: bool = False, route: int = 0) -> torch.Tensor:
+    """relu?(bn(weight2d @ x) [+ residual | + res_bn(residual)]) from one call of the extension.  route 0: the
+    matrix-core kernel that applies the tail to the product before storing it (ONE launch) where it takes the shapes
+    (plane size a multiple of 8), else conv1x1_f16 followed by the batch-norm tail in place (two launches);
+    route 1 / 2: that kernel / the two launches, explicitly."""
     global _conv1x1_bn_fn
     if _conv1x1_bn_fn is None:
         _conv1x1_bn_fn = spice_ops().conv1x1_bn_act
     if res_bn is None:
         return _conv1x1_bn_fn(x, weight2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, residual,
-                              None, None, None, None, 0.0, relu)
+                              None, None, None, None, 0.0, relu, route)
     return _conv1x1_bn_fn(x, weight2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, residual,
-                          res_bn.running_mean, res_bn.running_var, res_bn.weight, res_bn.bias, res_bn.eps, relu)
+                          res_bn.running_mean, res_bn.running_var, res_bn.weight, res_bn.bias, res_bn.eps, relu, route)

@@ -1,0 +1,129 @@
+"""The one-launch 1x1 convolution + batch-norm tail (matrix-core kernel, spice_conv1x1_bn_act_f16) against the
+two-launch route it replaces and against fp64 sums.
+
+On integer-valued fp16 data every product and every fp32 partial sum is exact, so the stored product does not
+depend on the order of the sums: there the fused kernel must equal the two launches BIT FOR BIT (this pins the
+operand layouts, the tile edges and the tail).  On random data the two routes may round the product to different
+fp16 neighbours where fp32 sums of another order land on the other side of a tie: a bounded number of elements,
+each within the tail's amplification of one fp16 step."""
+import ctypes
+
+import pytest
+import torch
+
+from spice_amd import _native as nat
+from spice_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    nat.lib()
+    return torch.device("cuda:0")
+
+
+def _norm(c, g, dev, eps=1e-5):
+    bn = torch.nn.BatchNorm2d(c, eps=eps).eval()
+    bn.running_mean.copy_(torch.randn(c, generator=g))
+    bn.running_var.copy_(torch.rand(c, generator=g) * 2 + 0.05)
+    bn.weight.data.copy_(torch.rand(c, generator=g) + 0.5)
+    bn.bias.data.copy_(torch.randn(c, generator=g))
+    return bn.to(dev)
+
+
+# n, cin, h, w, cout: whole tiles; K, M and pixel tails; a K that is not a multiple of 8 (unaligned weight rows);
+# tiny; deep K; a tile count that is not a multiple of 8; several row tiles
+SHAPES = [(2, 64, 16, 16, 256), (1, 40, 8, 24, 130), (3, 230, 4, 6, 77), (1, 8, 2, 4, 5), (2, 2048, 32, 32, 512),
+          (3, 96, 8, 40, 300), (1, 33, 16, 8, 64), (8, 256, 32, 32, 48)]
+
+
+def _integer_case(shape, dev):
+    n, cin, h, w, cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randint(-3, 4, (n, cin, h, w), generator=g).half()
+    wt = torch.randint(-2, 3, (cout, cin), generator=g).half()
+    exact = torch.einsum("oc,nchw->nohw", wt.double(), x.double())
+    return g, x.to(dev), wt.to(dev), exact.half().contiguous().to(dev)   # |sums| <= 6 * 2048: exact in fp32, one rounding to fp16
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_fused_plain_product_is_exact_on_integer_data(dev, shape):
+    """mean == NULL through the raw C ABI: the product alone, every tile edge."""
+    n, cin, h, w, cout = shape
+    _, x, wt, product = _integer_case(shape, dev)
+    y = torch.full((n, cout, h, w), float("nan"), dtype=torch.float16, device=dev)
+    guard = torch.full((4096,), 7.0, dtype=torch.float16, device=dev)   # allocated right behind y: must stay untouched
+    null = ctypes.c_void_p(0)
+    rc = nat.lib().spice_conv1x1_bn_act_f16(x.data_ptr(), wt.data_ptr(), y.data_ptr(), n, cin, h * w, cout, null, null,
+                                            null, null, 0.0, null, null, null, null, null, 0.0, 0,
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, product)
+    assert bool((guard == 7.0).all())
+    assert torch.equal(ops.conv1x1_f16(x, wt), product)   # the hipBLASLt product is exact on this data as well
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("mode", ["bn", "bn_relu", "res_relu", "dual_relu", "dual"])
+def test_fused_equals_two_launches_on_integer_data(dev, shape, mode):
+    n, cin, h, w, cout = shape
+    g, x, wt, product = _integer_case(shape, dev)
+    bn = _norm(cout, g, dev)
+    res = (2.0 * torch.randn(n, cout, h, w, generator=g)).half().to(dev) if mode != "bn" and mode != "bn_relu" else None
+    rbn = _norm(cout, g, dev, eps=1e-3) if mode.startswith("dual") else None
+    relu = mode.endswith("relu")
+    with torch.no_grad():
+        got = ops.conv1x1_bn_act(x, wt, bn, res, rbn, relu, route=1)
+        two = ops.conv1x1_bn_act(x, wt, bn, res, rbn, relu, route=2)
+        want = ops.bn_act_dual(product, bn, res, rbn, relu=relu) if rbn is not None else \
+            ops.bn_act(product, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, residual=res, relu=relu)
+    assert got.dtype == torch.float16 and got.shape == (n, cout, h, w)
+    assert torch.equal(got, want)
+    assert torch.equal(two, want)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16, 256), (8, 256, 128, 128, 64), (3, 230, 4, 6, 77), (2, 2048, 32, 32, 512),
+                                   (2, 512, 32, 32, 2048), (8, 304, 128, 128, 256)])
+def test_fused_on_random_data(dev, shape):
+    """Against fp64 sums of the fp16 values through the oracle's tail, and against the two-launch route."""
+    from oracle import bnact as ob
+    n, cin, h, w, cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + 5)
+    x = torch.randn(n, cin, h, w, generator=g).half()
+    wt = (torch.randn(cout, cin, generator=g) / cin ** 0.5).half()
+    res = torch.randn(n, cout, h, w, generator=g).half()
+    bn = _norm(cout, g, "cpu")
+    exact = torch.einsum("oc,nchw->nohw", wt.double(), x.double()).half().contiguous()
+    want = ob.bn_act(exact, bn.running_mean, bn.running_var, bn.weight.data, bn.bias.data, bn.eps, residual=res, relu=True)
+    bn = bn.to(dev)
+    with torch.no_grad():
+        got = ops.conv1x1_bn_act(x.to(dev), wt.to(dev), bn, res.to(dev), None, True, route=1)
+        two = ops.conv1x1_bn_act(x.to(dev), wt.to(dev), bn, res.to(dev), None, True, route=2)
+    # one fp16 step of the product (|product| <~ 5) times the largest scale of the norm (1.5 / sqrt(0.05) = 6.7), plus the
+    # steps of the two roundings of the tail
+    bound = 2.0 ** -9 * 6.7 + 2.0 ** -10 * float(want.float().abs().max()) * 2
+    assert float((got.float().cpu() - want.float()).abs().max()) <= bound
+    assert float((got.float() - two.float()).abs().max()) <= bound
+    assert float((got != two).float().mean()) < 0.02   # the routes differ only where a sum sits on a rounding tie
+
+
+def test_fused_rejects_what_it_cannot_take(dev):
+    x = torch.randn(1, 8, 2, 3, device=dev).half()      # 6 pixels per plane: not a multiple of 8
+    wt = torch.randn(4, 8, device=dev).half()
+    bn = _norm(4, torch.Generator().manual_seed(0), dev)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError):
+            ops.conv1x1_bn_act(x, wt, bn, None, None, True, route=1)
+        two = ops.conv1x1_bn_act(x, wt, bn, None, None, True, route=2)
+        auto = ops.conv1x1_bn_act(x, wt, bn, None, None, True)     # falls back to the two launches by itself
+        assert torch.equal(auto, two)
+        with pytest.raises(TypeError):
+            ops.conv1x1_bn_act(x.float(), wt, bn, None, None, True)
+        with pytest.raises(ValueError):
+            ops.conv1x1_bn_act(x, wt[:, :3].contiguous(), bn, None, None, True)
+        with pytest.raises(ValueError):
+            ops.conv1x1_bn_act(x, wt, bn, None, None, True, route=5)
+        assert ops.conv1x1_bn_act(x[:0], wt, bn, None, None, True).shape == (0, 4, 2, 3)

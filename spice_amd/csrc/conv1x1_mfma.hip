@@ -67,8 +67,43 @@ __device__ __forceinline__ unsigned mm_tile_of_block(unsigned id, unsigned total
 // on eight different 32-byte bank ranges once the pieces of rows with bit 1 set are exchanged pairwise.
 __device__ __forceinline__ int mm_b_offset(int k, int piece) { return k * kMmBPitch + ((piece ^ ((k & 2) << 1)) << 3); }
 
-template <bool A_VEC>
-__global__ __launch_bounds__(kMmThreads, 4) void conv1x1_bn_act_mfma_kernel(MmArgs a) {
+// STAGES: K steps whose pieces are in flight in registers ahead of the step being multiplied.  One stage leaves
+// room for four workgroups per compute unit (the others' loads hide this one's latency: the case of many tiles);
+// three stages are for deep K on few tiles, where a compute unit holds one or two workgroups and a step's
+// products take a fraction of a memory round trip.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+// bn_tail of bn_math.h for two neighbouring pixels of one channel at once, value for value the same: the fp32 steps
+// as packed operations, every rounding to fp16 a conversion of its own (never folded into the multiply-add before
+// it), the clamp on the rounded halves (rounding is monotonic and keeps 0 and NaN, so max-then-round and
+// round-then-max agree).
+template <bool HAS_RES, bool RES_BN>
+__device__ __forceinline__ half2_t bn_tail_pair(half2_t x, half2_t r, const BnChannel &p, const BnChannel &q, int relu) {
+    const float2_t xf = {static_cast<float>(x[0]), static_cast<float>(x[1])};
+    const float2_t t = (xf - float2_t{p.mean, p.mean}) * float2_t{p.inv, p.inv};
+    float2_t o = __builtin_elementwise_fma(float2_t{p.weight, p.weight}, t, float2_t{p.bias, p.bias});
+    asm volatile("" : "+v"(o));
+    half2_t v = {static_cast<_Float16>(o[0]), static_cast<_Float16>(o[1])};
+    if constexpr (HAS_RES) {
+        float2_t rf = {static_cast<float>(r[0]), static_cast<float>(r[1])};
+        if constexpr (RES_BN) {
+            const float2_t rt = (rf - float2_t{q.mean, q.mean}) * float2_t{q.inv, q.inv};
+            float2_t ro = __builtin_elementwise_fma(float2_t{q.weight, q.weight}, rt, float2_t{q.bias, q.bias});
+            asm volatile("" : "+v"(ro));
+            const half2_t rh = {static_cast<_Float16>(ro[0]), static_cast<_Float16>(ro[1])};
+            rf = float2_t{static_cast<float>(rh[0]), static_cast<float>(rh[1])};
+        }
+        float2_t sum = float2_t{static_cast<float>(v[0]), static_cast<float>(v[1])} + rf;
+        asm volatile("" : "+v"(sum));
+        v = half2_t{static_cast<_Float16>(sum[0]), static_cast<_Float16>(sum[1])};
+    }
+    if (relu) v = __builtin_elementwise_maximum(v, half2_t{0, 0});   // NaN-propagating maximum
+    return v;
+}
+
+template <bool A_VEC, int STAGES>
+__global__ __launch_bounds__(kMmThreads, STAGES == 1 ? 4 : 2) void conv1x1_bn_act_mfma_kernel(MmArgs a) {
     __shared__ __attribute__((aligned(16))) _Float16 lds[kMmLdsHalfs];
     _Float16 *As = lds;
     _Float16 *Bs = lds + kMmBM * kMmAPitch;
@@ -88,21 +123,12 @@ __global__ __launch_bounds__(kMmThreads, 4) void conv1x1_bn_act_mfma_kernel(MmAr
     const int e_p = n0 + e_pc;
     const bool has_bn = a.mean != nullptr, has_res = a.res != nullptr, res_bn = a.r_mean != nullptr;
     uint4 rres[4];
-    if (has_res) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + e_row + 32 * i;
-            rres[i] = make_uint4(0, 0, 0, 0);
-            if (m < a.M && e_p < a.hw)
-                rres[i] = *reinterpret_cast<const uint4 *>(a.res + (img * a.M + m) * static_cast<size_t>(a.hw) + e_p);
-        }
-    }
 
     const _Float16 *xi = a.x + img * static_cast<size_t>(a.K) * a.hw;
 
     // global -> register staging per K step: four 16-byte pieces of A and two of B per lane
-    uint4 ra[4], rb[2];
-    auto load_step = [&](int k0) {
+    uint4 ra_all[STAGES][4], rb_all[STAGES][2];
+    auto load_step = [&](int k0, uint4 (&ra)[4], uint4 (&rb)[2]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + kMmThreads * i;
@@ -130,7 +156,7 @@ __global__ __launch_bounds__(kMmThreads, 4) void conv1x1_bn_act_mfma_kernel(MmAr
                 rb[i] = *reinterpret_cast<const uint4 *>(xi + static_cast<size_t>(kk) * a.hw + p);
         }
     };
-    auto store_step = [&]() {
+    auto store_step = [&](const uint4 (&ra)[4], const uint4 (&rb)[2]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + kMmThreads * i;
@@ -157,29 +183,49 @@ __global__ __launch_bounds__(kMmThreads, 4) void conv1x1_bn_act_mfma_kernel(MmAr
     const int x_row = 8 * h + g_q;                                      // + 16 s (+ 4 for the second read)
     const bool wave_has_rows = m0 + 32 * wave < a.M;   // uniform per wave
 
-    load_step(0);
-    for (int k0 = 0; k0 < a.K; k0 += kMmBK) {
-        __syncthreads();   // every wave has read the previous step's images
-        store_step();
-        __syncthreads();
-        if (k0 + kMmBK < a.K) load_step(k0 + kMmBK);   // in flight during the products below
-        if (wave_has_rows) {
+    auto multiply_step = [&]() {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const half8_t fw = *reinterpret_cast<const half8_t *>(As + w_off + 16 * s);
-                half8_t fx[2];
+        for (int s = 0; s < 4; ++s) {
+            const half8_t fw = *reinterpret_cast<const half8_t *>(As + w_off + 16 * s);
+            half8_t fx[2];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    // pixels 32 t + 16 g_b + 4 g_p ..: piece 4 t + 2 g_b + (g_p >> 1), second half of it for odd g_p
-                    const int piece = 4 * t + 2 * g_b + (g_p >> 1), within = 4 * (g_p & 1);
-                    const int k_lo = 16 * s + x_row, k_hi = k_lo + 4;
-                    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(Bs + mm_b_offset(k_lo, piece) + within));
-                    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(Bs + mm_b_offset(k_hi, piece) + within));
-                    const short8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    fx[t] = __builtin_bit_cast(half8_t, both);
-                }
+            for (int t = 0; t < 2; ++t) {
+                // pixels 32 t + 16 g_b + 4 g_p ..: piece 4 t + 2 g_b + (g_p >> 1), second half of it for odd g_p
+                const int piece = 4 * t + 2 * g_b + (g_p >> 1), within = 4 * (g_p & 1);
+                const int k_lo = 16 * s + x_row, k_hi = k_lo + 4;
+                const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(Bs + mm_b_offset(k_lo, piece) + within));
+                const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(Bs + mm_b_offset(k_hi, piece) + within));
+                const short8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                fx[t] = __builtin_bit_cast(half8_t, both);
+            }
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fx[t], fw, acc[t], 0, 0, 0);
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fx[t], fw, acc[t], 0, 0, 0);
+        }
+    };
+
+#pragma unroll
+    for (int st = 0; st < STAGES; ++st)
+        if (st == 0 || st * kMmBK < a.K) load_step(st * kMmBK, ra_all[st], rb_all[st]);
+    // the residual's pieces, requested after the first K steps' so that waiting for those does not wait for these
+    if (has_res) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + e_row + 32 * i;
+            rres[i] = make_uint4(0, 0, 0, 0);
+            if (m < a.M && e_p < a.hw)
+                rres[i] = *reinterpret_cast<const uint4 *>(a.res + (img * a.M + m) * static_cast<size_t>(a.hw) + e_p);
+        }
+    }
+    for (int k0 = 0; k0 < a.K; k0 += STAGES * kMmBK) {
+#pragma unroll
+        for (int st = 0; st < STAGES; ++st) {
+            const int k = k0 + st * kMmBK;
+            if (k < a.K) {   // uniform
+                __syncthreads();   // every wave has read the previous step's images
+                store_step(ra_all[st], rb_all[st]);
+                __syncthreads();
+                if (k + STAGES * kMmBK < a.K) load_step(k + STAGES * kMmBK, ra_all[st], rb_all[st]);   // in flight from here
+                if (wave_has_rows) multiply_step();
             }
         }
     }
@@ -216,24 +262,33 @@ __global__ __launch_bounds__(kMmThreads, 4) void conv1x1_bn_act_mfma_kernel(MmAr
                 if (res_bn) {
                     const BnChannel qch = bn_channel_of(a.r_mean, a.r_var, a.r_weight, a.r_bias, a.r_eps, m);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        v[e] = static_cast<_Float16>(bn_tail<_Float16, true, true>(static_cast<float>(v[e]),
-                                                                                   static_cast<float>(r[e]), pch, qch, a.relu));
+                    for (int e = 0; e < 8; e += 2) {
+                        const half2_t o = bn_tail_pair<true, true>(half2_t{v[e], v[e + 1]}, half2_t{r[e], r[e + 1]}, pch, qch, a.relu);
+                        v[e] = o[0];
+                        v[e + 1] = o[1];
+                    }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        v[e] = static_cast<_Float16>(bn_tail<_Float16, true, false>(static_cast<float>(v[e]),
-                                                                                    static_cast<float>(r[e]), pch, pch, a.relu));
+                    for (int e = 0; e < 8; e += 2) {
+                        const half2_t o = bn_tail_pair<true, false>(half2_t{v[e], v[e + 1]}, half2_t{r[e], r[e + 1]}, pch, pch, a.relu);
+                        v[e] = o[0];
+                        v[e + 1] = o[1];
+                    }
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    v[e] = static_cast<_Float16>(bn_tail<_Float16, false, false>(static_cast<float>(v[e]), 0.0f, pch, pch, a.relu));
+                for (int e = 0; e < 8; e += 2) {
+                    const half2_t o = bn_tail_pair<false, false>(half2_t{v[e], v[e + 1]}, half2_t{0, 0}, pch, pch, a.relu);
+                    v[e] = o[0];
+                    v[e + 1] = o[1];
+                }
             }
         }
         *reinterpret_cast<half8_t *>(a.y + at) = v;
     }
 }
+
+SPICE_ENV_KNOB(mm_stages_knob, "SPICE_CONV1X1_STAGES", 0)
 
 }  // namespace spice
 
@@ -280,10 +335,19 @@ extern "C" int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void 
     a.relu = relu ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(a.total_tiles), block(kMmThreads);
-    if ((cin & 7) == 0 && aligned16(weight))
-        hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<true>), grid, block, 0, st, a);
+    // deep K on a grid that leaves a compute unit one or two workgroups: keep three K steps in flight
+    const long forced = mm_stages_knob();
+    const bool deep = forced > 0 ? forced >= 3
+                                 : (cin >= 4 * kMmBK && static_cast<int64_t>(a.total_tiles) <= 2 * static_cast<int64_t>(device_cu_count()));
+    const bool vec = (cin & 7) == 0 && aligned16(weight);
+    if (vec && deep)
+        hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<true, 3>), grid, block, 0, st, a);
+    else if (vec)
+        hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<true, 1>), grid, block, 0, st, a);
+    else if (deep)
+        hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<false, 3>), grid, block, 0, st, a);
     else
-        hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<false>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<false, 1>), grid, block, 0, st, a);
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;
 }

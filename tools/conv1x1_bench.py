@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--routes", default="1,2")
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--plain", action="store_true")
     args = ap.parse_args()
     routes = [int(r) for r in args.routes.split(",")]
     dev = torch.device("cuda:0")
@@ -64,6 +65,26 @@ def main():
                 row[f"route{r}_us"] = round(us, 1)
                 row[f"route{r}_GBps"] = round(mbytes / us * 1e3, 0)
                 total[r] += us * count
+        if args.plain:   # the product alone through the same kernel (no tail, no residual): what the tail costs
+            import ctypes
+            from spice_amd import _native as nat
+            null = ctypes.c_void_p(0)
+            y = torch.empty(args.batch, cout, side, side, device=dev, dtype=torch.float16)
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            call = lambda i: nat.lib().spice_conv1x1_bn_act_f16(xs[i % n_buf].data_ptr(), w.data_ptr(), y.data_ptr(), args.batch, cin,
+                                                                 side * side, cout, null, null, null, null, 0.0, null, null, null,
+                                                                 null, null, 0.0, 0, stream)
+            for i in range(3):
+                call(i)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for i in range(args.iters):
+                call(i)
+            e1.record()
+            torch.cuda.synchronize()
+            row["plain_us"] = round(1e3 * e0.elapsed_time(e1) / args.iters, 1)
+            row["plain_MB"] = round(2 * p * (cin + cout) / 1e6, 1)
         rows.append(row)
         print(json.dumps(row), flush=True)
     print(json.dumps({"per_forward_us": {f"route{r}": round(v, 1) for r, v in total.items()}}))

@@ -11,10 +11,10 @@
 // laid out for traffic first: X is read once per 128 output channels in 16-byte pieces, the product never
 // goes to memory in fp32 or un-normalised, the residual and Y move in 16-byte pieces.
 //
-// Workgroup: 256 lanes = 4 waves on a 128 (channels) x 64 (pixels of one image) tile, K in steps of 64.
-//   LDS   A[128][72]  weights, K contiguous (144-byte rows: a ds_read_b128 of 16 consecutive rows covers all 64 banks once)
+// Workgroup: 256 lanes = 4 waves on a 128 or 256 (channels) x 64 (pixels of one image) tile, K in steps of 64.
+//   LDS   A[128 | 256][72]  weights, K contiguous (144-byte rows: a ds_read_b128 of 16 consecutive rows covers all 64 banks once)
 //         B[64][64]   activations as they lie in memory, pixels contiguous, 16-byte pieces XOR-swizzled by the row
-//   wave w owns channels 32 w .. +31 and all 64 pixels: two v_mfma_f32_32x32x16_f16 per 16 of K, with the PIXELS as
+//   wave w owns channels 32 w .. +31 (or 64 w .. +63) and all 64 pixels: two (four) v_mfma_f32_32x32x16_f16 per 16 of K, with the PIXELS as
 //   the rows of the product (so that a lane ends up holding four consecutive pixels of one channel):
 //         A operand: lane l holds X^T[pixel l & 31][k = 8 (l >> 5) + 0..7]      two ds_read_b64_tr_b16, which hand each
 //                    lane a COLUMN of a 4 x 16 block of the pixel-contiguous image
@@ -31,8 +31,6 @@ constexpr int kMmBM = 128, kMmBN = 64, kMmBK = 64;
 constexpr int kMmAPitch = 72;    // halfs
 constexpr int kMmBPitch = 64;    // halfs (swizzled, no padding)
 constexpr int kMmCPitch = 72;    // halfs
-constexpr int kMmLdsHalfs = kMmBM * kMmAPitch + kMmBK * kMmBPitch;   // 26,624 bytes; the C image reuses the front
-static_assert(kMmBM * kMmCPitch <= kMmLdsHalfs, "the C image fits in the A and B images' storage");
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
@@ -102,35 +100,39 @@ __device__ __forceinline__ half2_t bn_tail_pair(half2_t x, half2_t r, const BnCh
     return v;
 }
 
-template <bool A_VEC, int STAGES>
-__global__ __launch_bounds__(kMmThreads, STAGES == 1 ? 4 : 2) void conv1x1_bn_act_mfma_kernel(MmArgs a) {
-    __shared__ __attribute__((aligned(16))) _Float16 lds[kMmLdsHalfs];
+template <bool A_VEC, int STAGES, int MT>
+__global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void conv1x1_bn_act_mfma_kernel(MmArgs a) {
+    constexpr int BM = kMmBM * MT;          // channels per workgroup: MT 32-channel product tiles per wave
+    constexpr int A_PIECES = 4 * MT;        // 16-byte pieces of A per lane and K step
+    constexpr int ROWS = 4 * MT;            // rows per lane in the row-major pass of the epilogue
+    __shared__ __attribute__((aligned(16))) _Float16 lds[BM * kMmAPitch + kMmBK * kMmBPitch];
+    static_assert(kMmCPitch <= kMmAPitch, "the C image fits in the A image's storage");
     _Float16 *As = lds;
-    _Float16 *Bs = lds + kMmBM * kMmAPitch;
+    _Float16 *Bs = lds + BM * kMmAPitch;
 
     const unsigned tile = mm_tile_of_block(blockIdx.x, a.total_tiles);
     const int mt = static_cast<int>(tile % static_cast<unsigned>(a.tiles_m));
     const unsigned rest = tile / static_cast<unsigned>(a.tiles_m);
     const int nt = static_cast<int>(rest % static_cast<unsigned>(a.tiles_n));
     const size_t img = rest / static_cast<unsigned>(a.tiles_n);
-    const int m0 = mt * kMmBM, n0 = nt * kMmBN;
+    const int m0 = mt * BM, n0 = nt * kMmBN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
 
-    // the row-major pass of the epilogue: lane takes 8 consecutive pixels of one channel, 4 such pieces
+    // the row-major pass of the epilogue: lane takes 8 consecutive pixels of one channel, ROWS such pieces
     const int e_pc = (tid & 7) * 8, e_row = tid >> 3;   // rows e_row + 32 i
     const int e_p = n0 + e_pc;
     const bool has_bn = a.mean != nullptr, has_res = a.res != nullptr, res_bn = a.r_mean != nullptr;
-    uint4 rres[4];
+    uint4 rres[ROWS];
 
     const _Float16 *xi = a.x + img * static_cast<size_t>(a.K) * a.hw;
 
-    // global -> register staging per K step: four 16-byte pieces of A and two of B per lane
-    uint4 ra_all[STAGES][4], rb_all[STAGES][2];
-    auto load_step = [&](int k0, uint4 (&ra)[4], uint4 (&rb)[2]) {
+    // global -> register staging per K step: A_PIECES 16-byte pieces of A and two of B per lane
+    uint4 ra_all[STAGES][A_PIECES], rb_all[STAGES][2];
+    auto load_step = [&](int k0, uint4 (&ra)[A_PIECES], uint4 (&rb)[2]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < A_PIECES; ++i) {
             const int c = tid + kMmThreads * i;
             const int m = m0 + (c >> 3), k = k0 + (c & 7) * 8;
             ra[i] = make_uint4(0, 0, 0, 0);
@@ -156,9 +158,9 @@ __global__ __launch_bounds__(kMmThreads, STAGES == 1 ? 4 : 2) void conv1x1_bn_ac
                 rb[i] = *reinterpret_cast<const uint4 *>(xi + static_cast<size_t>(kk) * a.hw + p);
         }
     };
-    auto store_step = [&](const uint4 (&ra)[4], const uint4 (&rb)[2]) {
+    auto store_step = [&](const uint4 (&ra)[A_PIECES], const uint4 (&rb)[2]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < A_PIECES; ++i) {
             const int c = tid + kMmThreads * i;
             *reinterpret_cast<uint4 *>(As + (c >> 3) * kMmAPitch + (c & 7) * 8) = ra[i];
         }
@@ -169,25 +171,32 @@ __global__ __launch_bounds__(kMmThreads, STAGES == 1 ? 4 : 2) void conv1x1_bn_ac
         }
     };
 
-    float16_t acc[2];
+    float16_t acc[MT][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][t][r] = 0.0f;
 
     // operand addresses inside the LDS images (halfs), without the K-step part
     const int h = lane >> 5;
-    const int w_off = (32 * wave + (lane & 31)) * kMmAPitch + 8 * h;   // + 16 s
+    const int wave_row = 32 * MT * wave;                                  // first channel of the wave inside the tile
+    const int w_off = (wave_row + (lane & 31)) * kMmAPitch + 8 * h;       // + 32 mi rows + 16 s
     // transposed read: lane 4q + p of a 16-lane group supplies row q, pixels 4p .. 4p+3 of the group's 16 pixels
     const int g_b = (lane >> 4) & 1, g_q = (lane & 15) >> 2, g_p = lane & 3;
-    const int x_row = 8 * h + g_q;                                      // + 16 s (+ 4 for the second read)
-    const bool wave_has_rows = m0 + 32 * wave < a.M;   // uniform per wave
+    const int x_row = 8 * h + g_q;                                        // + 16 s (+ 4 for the second read)
+    bool has_rows[MT];   // uniform per wave
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) has_rows[mi] = m0 + wave_row + 32 * mi < a.M;
 
     auto multiply_step = [&]() {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const half8_t fw = *reinterpret_cast<const half8_t *>(As + w_off + 16 * s);
-            half8_t fx[2];
+            half8_t fw[MT], fx[2];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+                fw[mi] = *reinterpret_cast<const half8_t *>(As + w_off + 32 * mi * kMmAPitch + 16 * s);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 // pixels 32 t + 16 g_b + 4 g_p ..: piece 4 t + 2 g_b + (g_p >> 1), second half of it for odd g_p
@@ -199,7 +208,12 @@ __global__ __launch_bounds__(kMmThreads, STAGES == 1 ? 4 : 2) void conv1x1_bn_ac
                 fx[t] = __builtin_bit_cast(half8_t, both);
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fx[t], fw, acc[t], 0, 0, 0);
+            for (int mi = 0; mi < MT; ++mi)
+                if (has_rows[mi]) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fx[t], fw[mi], acc[mi][t], 0, 0, 0);
+                }
         }
     };
 
@@ -209,7 +223,7 @@ __global__ __launch_bounds__(kMmThreads, STAGES == 1 ? 4 : 2) void conv1x1_bn_ac
     // the residual's pieces, requested after the first K steps' so that waiting for those does not wait for these
     if (has_res) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < ROWS; ++i) {
             const int m = m0 + e_row + 32 * i;
             rres[i] = make_uint4(0, 0, 0, 0);
             if (m < a.M && e_p < a.hw)
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(kMmThreads, STAGES == 1 ? 4 : 2) void conv1x1_bn_ac
                 store_step(ra_all[st], rb_all[st]);
                 __syncthreads();
                 if (k + STAGES * kMmBK < a.K) load_step(k + STAGES * kMmBK, ra_all[st], rb_all[st]);   // in flight from here
-                if (wave_has_rows) multiply_step();
+                multiply_step();
             }
         }
     }
@@ -233,23 +247,25 @@ __global__ __launch_bounds__(kMmThreads, STAGES == 1 ? 4 : 2) void conv1x1_bn_ac
     // accumulators -> fp16 (the rounding of a stored product) -> C image [channel][pixel], four pixels per write
     __syncthreads();
     _Float16 *Cs = lds;
-    if (wave_has_rows) {
-        const int row = 32 * wave + (lane & 31);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+    for (int mi = 0; mi < MT; ++mi)
+        if (has_rows[mi]) {
+            const int row = wave_row + 32 * mi + (lane & 31);
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                half4_t v;
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = static_cast<_Float16>(acc[t][4 * rq + e]);
-                *reinterpret_cast<half4_t *>(Cs + row * kMmCPitch + 32 * t + 8 * rq + 4 * h) = v;
-            }
-    }
+                for (int rq = 0; rq < 4; ++rq) {
+                    half4_t v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = static_cast<_Float16>(acc[mi][t][4 * rq + e]);
+                    *reinterpret_cast<half4_t *>(Cs + row * kMmCPitch + 32 * t + 8 * rq + 4 * h) = v;
+                }
+        }
     __syncthreads();
 
     if (e_p >= a.hw) return;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ROWS; ++i) {
         const int row = e_row + 32 * i;
         const int m = m0 + row;
         if (m >= a.M) break;   // rows ascend with i
@@ -289,6 +305,7 @@ __global__ __launch_bounds__(kMmThreads, STAGES == 1 ? 4 : 2) void conv1x1_bn_ac
 }
 
 SPICE_ENV_KNOB(mm_stages_knob, "SPICE_CONV1X1_STAGES", 0)
+SPICE_ENV_KNOB(mm_mt_knob, "SPICE_CONV1X1_MT", 0)
 
 }  // namespace spice
 
@@ -309,7 +326,13 @@ extern "C" int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void 
     if ((hw & 7) != 0 || !aligned16(x) || !aligned16(y) || (residual != nullptr && !aligned16(residual)))
         return SPICE_ERR_UNSUPPORTED;
     if (cin > (1 << 20) || cout > (1 << 20) || hw > (1 << 28)) return SPICE_ERR_UNSUPPORTED;
-    const int64_t tiles_m = ceil_div(cout, kMmBM), tiles_n = ceil_div(hw, kMmBN);
+    const int64_t tiles_n = ceil_div(hw, kMmBN);
+    // 256-channel tiles (two product tiles per wave: half the reads of X and of the LDS images per product) are an
+    // option (SPICE_CONV1X1_MT=2), not the default: at 206 registers a compute unit holds two workgroups instead of
+    // four, which on MI355X costs more than the traffic saves on every pair of the DeepLabV3+-ResNet-50 forward
+    // but one (tools/conv1x1_bench.py: 958 us per forward against 850 us)
+    const bool wide = mm_mt_knob() >= 2 && cout > kMmBM;
+    const int64_t tiles_m = ceil_div(cout, wide ? 2 * kMmBM : kMmBM);
     if (tiles_m * tiles_n > INT32_MAX / n) return SPICE_ERR_UNSUPPORTED;
     MmArgs a;
     a.x = static_cast<const _Float16 *>(x);
@@ -337,17 +360,21 @@ extern "C" int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void 
     const dim3 grid(a.total_tiles), block(kMmThreads);
     // deep K on a grid that leaves a compute unit one or two workgroups: keep three K steps in flight
     const long forced = mm_stages_knob();
-    const bool deep = forced > 0 ? forced >= 3
-                                 : (cin >= 4 * kMmBK && static_cast<int64_t>(a.total_tiles) <= 2 * static_cast<int64_t>(device_cu_count()));
+    const bool deep = !wide && (forced > 0 ? forced >= 3
+                                           : (cin >= 4 * kMmBK && static_cast<int64_t>(a.total_tiles) <= 2 * static_cast<int64_t>(device_cu_count())));
     const bool vec = (cin & 7) == 0 && aligned16(weight);
-    if (vec && deep)
-        hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<true, 3>), grid, block, 0, st, a);
-    else if (vec)
-        hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<true, 1>), grid, block, 0, st, a);
-    else if (deep)
-        hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<false, 3>), grid, block, 0, st, a);
-    else
-        hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<false, 1>), grid, block, 0, st, a);
+#define SPICE_MM_LAUNCH(V, S, T) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, T>), grid, block, 0, st, a)
+    if (wide) {
+        if (vec) SPICE_MM_LAUNCH(true, 1, 2);
+        else SPICE_MM_LAUNCH(false, 1, 2);
+    } else if (deep) {
+        if (vec) SPICE_MM_LAUNCH(true, 3, 1);
+        else SPICE_MM_LAUNCH(false, 3, 1);
+    } else {
+        if (vec) SPICE_MM_LAUNCH(true, 1, 1);
+        else SPICE_MM_LAUNCH(false, 1, 1);
+    }
+#undef SPICE_MM_LAUNCH
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;
 }

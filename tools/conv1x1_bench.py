@@ -85,6 +85,15 @@ def main():
             torch.cuda.synchronize()
             row["plain_us"] = round(1e3 * e0.elapsed_time(e1) / args.iters, 1)
             row["plain_MB"] = round(2 * p * (cin + cout) / 1e6, 1)
+            for i in range(3):
+                ops.conv1x1_f16(xs[i % n_buf], w)
+            torch.cuda.synchronize()
+            e0.record()
+            for i in range(args.iters):
+                ops.conv1x1_f16(xs[i % n_buf], w)
+            e1.record()
+            torch.cuda.synchronize()
+            row["blaslt_us"] = round(1e3 * e0.elapsed_time(e1) / args.iters, 1)
         rows.append(row)
         print(json.dumps(row), flush=True)
     print(json.dumps({"per_forward_us": {f"route{r}": round(v, 1) for r, v in total.items()}}))

@@ -91,14 +91,21 @@ __global__ __launch_bounds__(kDwThreads) void depthwise3x3_kernel(DwArgs a) {
 // dilation and the width multiples of 4 a group lies entirely inside or entirely outside the plane.
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(kDwThreads) void depthwise3x3_dilated_kernel(DwArgs a, int dil) {
-    const int plane = blockIdx.x / a.blocks_per_plane;
-    const int band = blockIdx.x - plane * a.blocks_per_plane;
+// A plane smaller than the workgroup (32x32: 128 lanes) shares it with the next plane(s): `planes_per_block`.
+__global__ __launch_bounds__(kDwThreads) void depthwise3x3_dilated_kernel(DwArgs a, int dil, int planes_per_block,
+                                                                         int n_planes) {
+    const int lanes_per_plane = a.lanes_per_row * a.rows_per_block;
+    const int sub = planes_per_block > 1 ? static_cast<int>(threadIdx.x) / lanes_per_plane : 0;
+    const int t = static_cast<int>(threadIdx.x) - sub * lanes_per_plane;
+    const int plane_raw = planes_per_block > 1 ? static_cast<int>(blockIdx.x) * planes_per_block + sub
+                                               : static_cast<int>(blockIdx.x) / a.blocks_per_plane;
+    const int band = planes_per_block > 1 ? 0 : static_cast<int>(blockIdx.x) - plane_raw * a.blocks_per_plane;
+    const int plane = min(plane_raw, n_planes - 1);
     const int ch = plane % a.c;
-    const int ly = threadIdx.x / a.lanes_per_row;
-    const int lx = threadIdx.x - ly * a.lanes_per_row;
+    const int ly = t / a.lanes_per_row;
+    const int lx = t - ly * a.lanes_per_row;
     const int y = band * a.rows_per_block + ly;
-    const bool active = ly < a.rows_per_block && y < a.h;
+    const bool active = plane_raw < n_planes && sub < planes_per_block && ly < a.rows_per_block && y < a.h;
     const int yc = min(y, a.h - 1);
     const int x0 = lx * 8;
 
@@ -110,12 +117,13 @@ __global__ __launch_bounds__(kDwThreads) void depthwise3x3_dilated_kernel(DwArgs
         wt[k] = static_cast<float>(v);
     }
     const _Float16 *src = a.x + static_cast<int64_t>(plane) * a.h * a.wd;
+    // a group outside the plane is not loaded (with a dilation beyond the plane size that is every tap but the centre)
     f16x4_t g[3][3][2];
     bool ok[3][3][2];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const int yy = yc + (r - 1) * dil;
-        const bool row_in = yy >= 0 && yy < a.h;
+        const bool row_in = active && yy >= 0 && yy < a.h;
         const _Float16 *row = src + static_cast<int64_t>(min(max(yy, 0), a.h - 1)) * a.wd;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -123,7 +131,8 @@ __global__ __launch_bounds__(kDwThreads) void depthwise3x3_dilated_kernel(DwArgs
             for (int k = 0; k < 2; ++k) {
                 const int s = x0 + (j - 1) * dil + 4 * k;
                 ok[r][j][k] = row_in && s >= 0 && s + 4 <= a.wd;
-                g[r][j][k] = *reinterpret_cast<const f16x4_t *>(row + min(max(s, 0), a.wd - 4));
+                g[r][j][k] = f16x4_t{0, 0, 0, 0};
+                if (ok[r][j][k]) g[r][j][k] = *reinterpret_cast<const f16x4_t *>(row + s);
             }
     }
     float acc[8];
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(kDwThreads) void depthwise3x3_dilated_kernel(DwArgs
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float v = ok[r][j][e >> 2] ? static_cast<float>(g[r][j][e >> 2][e & 3]) : 0.0f;
+                const float v = static_cast<float>(g[r][j][e >> 2][e & 3]);   // 0 outside the plane: w * 0 leaves the sum
                 acc[e] = __builtin_fmaf(wt[r * 3 + j], v, acc[e]);
             }
     f16x8_t out;
@@ -191,9 +200,14 @@ static int spice_depthwise_common(const void *x, const void *weight, int32_t wei
     if (dilation == 1)
         hipLaunchKernelGGL(depthwise3x3_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kDwThreads), 0,
                            static_cast<hipStream_t>(stream), a);
-    else
-        hipLaunchKernelGGL(depthwise3x3_dilated_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kDwThreads), 0,
-                           static_cast<hipStream_t>(stream), a, dilation);
+    else {
+        // whole small planes side by side in one workgroup
+        const int lanes_per_plane = a.lanes_per_row * a.rows_per_block;
+        const int ppb = a.blocks_per_plane == 1 ? kDwThreads / lanes_per_plane : 1;
+        const int64_t grid = ppb > 1 ? ceil_div(n * c, ppb) : blocks;
+        hipLaunchKernelGGL(depthwise3x3_dilated_kernel, dim3(static_cast<unsigned>(grid)), dim3(kDwThreads), 0,
+                           static_cast<hipStream_t>(stream), a, dilation, ppb, static_cast<int>(n * c));
+    }
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;
 }

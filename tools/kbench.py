@@ -219,6 +219,17 @@ def main():
             report(f"torch conv2d depthwise {shp}", timed(fns, args.iters), nbytes)
             outs.clear()
 
+    if want("depthwise") or "depthwise_dilated" in only:
+        # the three dilated depthwise branches of the ASPP block: [8, 2048, 32, 32], dilation 12 / 24 / 36
+        shp = (8, 2048, 32, 32)
+        xs = [torch.randn(*shp, device=dev).half() for _ in range(5)]
+        wt = torch.randn(shp[1], 1, 3, 3, device=dev)
+        outs = []
+        for dil in (12, 24, 36):
+            fns = [lambda a=a: outs.append(ops.depthwise_conv3x3(a, wt, dil)) or (len(outs) > 2 and outs.pop(0)) for a in xs]
+            report(f"depthwise3x3 dilation {dil} {shp}", timed(fns, args.iters), xs[0].numel() * 4)
+            outs.clear()
+
     if want("bnact"):
         # the largest batch-norms of DeepLabV3+-R50 at the benchmark geometry: layer1 [8,256,128,128] fp16,
         # with and without the residual; torch's three kernels beside them

@@ -312,6 +312,17 @@ int spice_bn_act_dual(const void *x, const void *residual, void *y, int32_t dtyp
                       const float *r_var, const float *r_weight, const float *r_bias, float r_eps, int64_t n,
                       int64_t c, int64_t hw, int32_t relu, void *stream);
 
+/* The stem of a ResNet encoder behind its 7x7 convolution in one pass (pruning/models.py:35-39's ResNet encoders:
+ * bn1 -> relu -> maxpool):
+ *   full   = relu?( bn(x) )                          [n, c, h, w]      (NULL: not wanted, not written)
+ *   pooled = max_pool2d(full, 3, stride 2, padding 1) [n, c, h/2, w/2]
+ * fp16 NCHW; the batch-norm is spice_bn_act's arithmetic and the maximum keeps NaN as torch's kernel does, so both
+ * outputs equal those of the two launches bit for bit.  h must be even and w a multiple of 16 (else
+ * SPICE_ERR_UNSUPPORTED); neither output may be x. */
+int spice_bn_act_maxpool_f16(const void *x, void *full, void *pooled, const float *mean, const float *var,
+                             const float *weight, const float *bias, float eps, int64_t n, int64_t c, int32_t h,
+                             int32_t w, int32_t relu, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * (7) Depthwise 3x3 convolution (stride 1, padding 1, no bias), fp16 NCHW.
  *

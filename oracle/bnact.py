@@ -29,3 +29,11 @@ def bn_act_dual(x: torch.Tensor, bn, residual: torch.Tensor, res_bn, relu: bool 
     dtype = x.dtype
     r = bn_act(residual, *res_bn)
     return bn_act(x, *bn, residual=r.to(dtype), relu=relu)
+
+
+def bn_act_maxpool(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
+                   eps: float, relu: bool = True):
+    """(relu?(bn(x)), max_pool2d(that, 3, stride 2, padding 1)): the stem of the ResNet encoders behind their first
+    convolution, as its separate ops."""
+    full = bn_act(x, mean, var, weight, bias, eps, relu=relu)
+    return full, F.max_pool2d(full.float(), 3, 2, 1).to(full.dtype)

@@ -339,6 +339,29 @@ Tensor bn_act_dual(const Tensor &x, const Tensor &mean, const Tensor &var, const
     return out;
 }
 
+// (full, pooled) = (relu?(bn(x)), max_pool2d(that, 3, 2, 1)); `full` is an empty tensor when want_full is false
+std::tuple<Tensor, Tensor> bn_act_maxpool(const Tensor &x, const Tensor &mean, const Tensor &var, const Tensor &weight,
+                                          const Tensor &bias, double eps, bool relu, bool want_full) {
+    check_dev(x, "x", at::kHalf);
+    TORCH_CHECK_VALUE(x.dim() == 4 && x.is_contiguous(), "bn_act_maxpool: x must be a contiguous [N, C, H, W] tensor");
+    const int64_t n = x.size(0), c = x.size(1), h = x.size(2), w = x.size(3);
+    for (const Tensor *t : {&mean, &var, &weight, &bias})
+        TORCH_CHECK_TYPE(t->scalar_type() == at::kFloat && t->device() == x.device() && t->numel() == c &&
+                             t->is_contiguous(),
+                         "bn_act_maxpool: the four parameter vectors must be contiguous fp32 [", c, "] on ", x.device());
+    TORCH_CHECK_VALUE(h <= std::numeric_limits<int32_t>::max() && w <= std::numeric_limits<int32_t>::max(),
+                      "bn_act_maxpool: plane too large");
+    c10::DeviceGuard guard(x.device());
+    Tensor full = want_full ? at::empty_like(x) : at::empty({0}, x.options());
+    Tensor pooled = at::empty({n, c, h / 2, w / 2}, x.options());
+    check_rc(spice_bn_act_maxpool_f16(x.data_ptr(), want_full ? full.data_ptr() : nullptr, pooled.data_ptr(),
+                                      mean.data_ptr<float>(), var.data_ptr<float>(), weight.data_ptr<float>(),
+                                      bias.data_ptr<float>(), (float)eps, n, c, (int32_t)h, (int32_t)w, relu ? 1 : 0,
+                                      current_stream(x)),
+             "spice_bn_act_maxpool_f16");
+    return std::make_tuple(full, pooled);
+}
+
 Tensor depthwise_conv3x3(const Tensor &x, const Tensor &weight, int64_t dilation) {
     check_dev(x, "x", at::kHalf);
     TORCH_CHECK_TYPE(weight.scalar_type() == at::kHalf || weight.scalar_type() == at::kFloat,
@@ -506,6 +529,8 @@ TORCH_LIBRARY(spice, m) {
           "bool relu) -> Tensor", &bn_act);
     m.def("bn_act_dual(Tensor x, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, Tensor residual, "
           "Tensor r_mean, Tensor r_var, Tensor r_weight, Tensor r_bias, float r_eps, bool relu) -> Tensor", &bn_act_dual);
+    m.def("bn_act_maxpool(Tensor x, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, bool relu, "
+          "bool want_full) -> (Tensor, Tensor)", &bn_act_maxpool);
     m.def("depthwise_conv3x3(Tensor x, Tensor weight, int dilation) -> Tensor", &depthwise_conv3x3);
     m.def("conv1x1_f16(Tensor x, Tensor weight2d) -> Tensor", &conv1x1_f16);
     m.def("conv1x1_bn_act(Tensor x, Tensor weight2d, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, "

@@ -30,4 +30,6 @@ def create_model(architecture: str, encoder_name: str, classes: int, in_channels
         head = SegmentationHead(decoder.out_channels, classes, kernel=1, upsampling=4)
     else:
         raise ValueError(f"Unsupported architecture: {architecture}")
+    if architecture in ("DeepLabV3Plus", "FPN") and hasattr(encoder, "skip_stem_feature"):
+        encoder.skip_stem_feature = True   # these decoders never read the stride-2 feature map
     return SegmentationModel(encoder, decoder, head, f"{architecture}-{encoder_name}")

@@ -6,6 +6,8 @@ from typing import List
 import torch
 import torch.nn as nn
 
+from .. import ops
+from . import layers
 from .layers import BatchNormAct2d, Conv1x1, conv1x1_bn
 
 
@@ -67,10 +69,29 @@ class ResNet50Encoder(nn.Module):
             layers.append(Bottleneck(self.inplanes, planes, 1, dilation))
         return nn.Sequential(*layers)
 
+    #: set by a model whose decoder never reads the first feature map (DeepLabV3+): the stem then does not store it
+    skip_stem_feature = False
+
+    def _stem(self, x):
+        """(bn1(conv1(x)), its max-pooling).  On the inference path of a HIP device the batch-norm, the ReLU and the
+        pooling are ONE launch over the convolution's result (ops.bn_act_maxpool: same values as the separate ops);
+        modules carrying hooks, symbolic tracing, training and every other situation run them one after the other."""
+        y = self.conv1(x)
+        mp = self.maxpool
+        if (isinstance(y, torch.Tensor) and layers.library_forward() and not torch.is_grad_enabled() and y.is_cuda
+                and not torch.nn.modules.module._global_forward_hooks
+                and not (layers._hooked(self.bn1) or layers._hooked(mp)) and layers._plain_inference_norm(self.bn1)
+                and type(mp) is nn.MaxPool2d and mp.kernel_size == 3 and mp.stride == 2 and mp.padding == 1
+                and mp.dilation == 1 and not mp.ceil_mode and not mp.return_indices
+                and ops.bn_act_maxpool_supported(y)):
+            return ops.bn_act_maxpool(y, self.bn1, relu=self.bn1.relu_after, want_full=not self.skip_stem_feature)
+        f1 = self.bn1(y)
+        return f1, mp(f1)
+
     def forward(self, x) -> List[torch.Tensor]:
         f0 = x
-        f1 = self.bn1(self.conv1(x))
-        f2 = self.layer1(self.maxpool(f1))
+        f1, pooled = self._stem(x)
+        f2 = self.layer1(pooled)
         f3 = self.layer2(f2)
         f4 = self.layer3(f3)
         f5 = self.layer4(f4)

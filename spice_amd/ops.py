@@ -429,6 +429,20 @@ def bn_act(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, weight: torch
     return _bn_fn(x, mean, var, weight, bias, eps, residual, relu)
 
 
+def bn_act_maxpool_supported(x: torch.Tensor) -> bool:
+    """Whether bn_act_maxpool takes this tensor: contiguous fp16 NCHW, even height, width a multiple of 16."""
+    return (x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float16 and x.shape[2] % 2 == 0
+            and x.shape[3] % 16 == 0 and x.shape[3] <= 4096)
+
+
+def bn_act_maxpool(x: torch.Tensor, bn: "torch.nn.BatchNorm2d", relu: bool = True, want_full: bool = True):
+    """(relu?(bn(x)), max_pool2d(that, kernel 3, stride 2, padding 1)) in one launch: the stem of a ResNet encoder
+    behind its first convolution.  With want_full=False the first tensor is not computed (None is returned)."""
+    full, pooled = spice_ops().bn_act_maxpool(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, relu,
+                                              want_full)
+    return (full if want_full else None), pooled
+
+
 _bn_dual_fn = None
 
 

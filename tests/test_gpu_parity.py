@@ -807,3 +807,69 @@ def test_bn_act_rejects_what_it_does_not_reproduce(dev):
     with pytest.raises(TypeError):
         ops.bn_act(x.float(), p[0].half(), *p[1:], 1e-5)
     assert ops.bn_act(x.float()[:0], *p, 1e-5).shape == (0, 4, 3, 3)
+
+
+@pytest.mark.parametrize("shape,relu,want_full", [((2, 5, 8, 16), True, True), ((1, 3, 2, 16), True, True),
+                                                   ((3, 7, 34, 48), False, True), ((8, 64, 256, 256), True, True),
+                                                   ((2, 64, 64, 128), True, False), ((1, 2, 6, 32), True, True)])
+def test_bn_act_maxpool_vs_oracle_and_torch(dev, shape, relu, want_full):
+    """The ResNet stem behind its first convolution in one launch: both outputs bit for bit what the batch-norm
+    launch and torch's max-pooling give on the device, and the CPU oracle's within the batch-norm's fp16 step.
+    NaN and infinities travel through the pooling as through torch's."""
+    from oracle import bnact as ob
+    g = torch.Generator().manual_seed(sum(shape))
+    c = shape[1]
+    bn = torch.nn.BatchNorm2d(c).eval()
+    bn.running_mean.copy_(torch.randn(c, generator=g))
+    bn.running_var.copy_(torch.rand(c, generator=g) * 2 + 0.05)
+    bn.weight.data.copy_(torch.rand(c, generator=g) + 0.5)
+    bn.bias.data.copy_(torch.randn(c, generator=g))
+    x = (2.0 * torch.randn(*shape, generator=g)).half()
+    x.view(-1)[::97] = float("nan")
+    x.view(-1)[5::193] = float("inf")
+    x.view(-1)[7::211] = float("-inf")
+    want_f, want_p = ob.bn_act_maxpool(x, bn.running_mean, bn.running_var, bn.weight.data, bn.bias.data, bn.eps, relu=relu)
+    bn = bn.to(dev)
+    with torch.no_grad():
+        full, pooled = ops.bn_act_maxpool(x.to(dev), bn, relu=relu, want_full=want_full)
+        there_f = ops.bn_act(x.to(dev), bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, relu=relu)
+        there_p = torch.nn.functional.max_pool2d(there_f, 3, 2, 1)
+    assert (full is None) == (not want_full)
+    same = lambda a, b: torch.equal(torch.nan_to_num(a.float(), nan=12345.0), torch.nan_to_num(b.float(), nan=12345.0))
+    assert pooled.shape == there_p.shape and pooled.dtype == torch.float16 and same(pooled, there_p)
+    if want_full:
+        assert same(full, there_f)
+    finite = torch.isfinite(want_p.float()) & torch.isfinite(pooled.float().cpu())
+    assert bool((torch.isnan(want_p) == torch.isnan(pooled.cpu())).all())
+    diff = (pooled.float().cpu() - want_p.float()).abs()[finite]
+    assert float(diff.max()) <= 4e-3 * max(1.0, float(want_p.float()[finite].abs().max()))
+
+
+def test_bn_act_maxpool_rejects_other_layouts(dev):
+    bn = torch.nn.BatchNorm2d(4).eval().to(dev)
+    assert not ops.bn_act_maxpool_supported(torch.zeros(1, 4, 7, 16, device=dev).half())     # odd height
+    assert not ops.bn_act_maxpool_supported(torch.zeros(1, 4, 8, 24, device=dev).half())     # width not a multiple of 16
+    with pytest.raises(RuntimeError):
+        ops.bn_act_maxpool(torch.zeros(1, 4, 7, 16, device=dev).half(), bn)
+    with pytest.raises(TypeError):
+        ops.bn_act_maxpool(torch.zeros(1, 4, 8, 16, device=dev), bn)
+    full, pooled = ops.bn_act_maxpool(torch.zeros(0, 4, 8, 16, device=dev).half(), bn)
+    assert full.shape == (0, 4, 8, 16) and pooled.shape == (0, 4, 4, 8)
+
+
+def test_resnet_stem_uses_one_launch_and_equals_the_modules(dev):
+    """The encoder's stem on the library path against its modules one after the other (hooks force that path)."""
+    from spice_amd.nets.resnet import ResNet50Encoder
+    torch.manual_seed(5)
+    enc = ResNet50Encoder(3, output_stride=16).to(dev).eval()
+    enc.bn1.running_mean.normal_(0.0, 0.2)
+    enc.bn1.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(2, 3, 64, 96, device=dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        f1, pooled = enc._stem(x)
+        handle = enc.maxpool.register_forward_hook(lambda m, i, o: None)
+        g1, gp = enc._stem(x)
+        handle.remove()
+        enc.skip_stem_feature = True
+        none, pooled2 = enc._stem(x)
+    assert none is None and torch.equal(pooled, gp) and torch.equal(f1, g1) and torch.equal(pooled2, gp)

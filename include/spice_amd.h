@@ -284,6 +284,15 @@ int spice_upsample_bilinear(const void *src, int32_t src_dtype, void *dst, int32
                             int32_t out_w, int32_t align_corners, float scale_h, float scale_w,
                             void *stream);
 
+/* The same into a channel slice of a larger tensor (the decoder's concatenation buffer, so that no separate
+ * concatenation pass is needed): the destination's planes lie in groups of planes_per_group contiguous planes
+ * (the channels of one image), the groups dst_group_stride elements apart.  planes must be a multiple of
+ * planes_per_group. */
+int spice_upsample_bilinear_into(const void *src, int32_t src_dtype, void *dst, int32_t dst_dtype,
+                                 int64_t planes, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
+                                 int32_t align_corners, float scale_h, float scale_w, int64_t planes_per_group,
+                                 int64_t dst_group_stride, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * (6) Inference batch-norm with the residual add and the ReLU behind it fused in.
  *
@@ -367,13 +376,14 @@ int spice_conv1x1_f16(const void *x, const void *weight, void *y, int64_t n, int
  * the tail is spice_bn_act's / spice_bn_act_dual's arithmetic, so the values are those of the two calls up to
  * the order of the fp32 sums.  mean == NULL: the plain product (no tail; residual must be NULL).
  * residual is [n, Cout, HW] fp16 or NULL; the r_* vectors are all NULL or all set (then residual is required).
- * HW must be a multiple of 8 and x, y, residual 16-byte aligned, else SPICE_ERR_UNSUPPORTED (callers then use
- * the two calls above).  Holds no state and uses no scratch memory. */
+ * y_image_stride: elements between the images of y (0 = Cout * HW, dense); larger when y is a channel slice of a
+ * concatenation buffer.  HW and y_image_stride must be multiples of 8 and x, y, residual 16-byte aligned, else
+ * SPICE_ERR_UNSUPPORTED (callers then use the two calls above).  Holds no state and uses no scratch memory. */
 int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int64_t hw,
                              int64_t cout, const float *mean, const float *var, const float *bn_weight,
                              const float *bn_bias, float eps, const void *residual, const float *r_mean,
                              const float *r_var, const float *r_weight, const float *r_bias, float r_eps,
-                             int32_t relu, void *stream);
+                             int32_t relu, int64_t y_image_stride, void *stream);
 
 #ifdef __cplusplus
 }

@@ -42,7 +42,8 @@ typedef __attribute__((address_space(3))) short4_t *lds_short4_ptr;
 struct MmArgs {
     const _Float16 *x;      // [n][K][hw]
     const _Float16 *w;      // [M][K]
-    _Float16 *y;            // [n][M][hw]
+    _Float16 *y;            // [n][M][hw], images y_image_stride elements apart (a channel slice of a larger tensor)
+    int64_t y_image_stride;
     const _Float16 *res;    // [n][M][hw] or null
     const float *mean, *var, *weight, *bias;           // null mean: no batch-norm, no tail
     const float *r_mean, *r_var, *r_weight, *r_bias;   // batch-norm of the residual, or null
@@ -270,7 +271,6 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
         const int m = m0 + row;
         if (m >= a.M) break;   // rows ascend with i
         half8_t v = *reinterpret_cast<const half8_t *>(Cs + row * kMmCPitch + e_pc);
-        const size_t at = (img * a.M + m) * static_cast<size_t>(a.hw) + e_p;
         if (has_bn) {
             const BnChannel pch = bn_channel_of(a.mean, a.var, a.weight, a.bias, a.eps, m);
             if (has_res) {
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
                 }
             }
         }
-        *reinterpret_cast<half8_t *>(a.y + at) = v;
+        *reinterpret_cast<half8_t *>(a.y + img * a.y_image_stride + static_cast<size_t>(m) * a.hw + e_p) = v;
     }
 }
 
@@ -313,7 +313,7 @@ extern "C" int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void 
                                         int64_t cout, const float *mean, const float *var, const float *bn_weight,
                                         const float *bn_bias, float eps, const void *residual, const float *r_mean,
                                         const float *r_var, const float *r_weight, const float *r_bias, float r_eps,
-                                        int32_t relu, void *stream) {
+                                        int32_t relu, int64_t y_image_stride, void *stream) {
     using namespace spice;
     if (n < 0 || cin <= 0 || hw < 0 || cout <= 0) return SPICE_ERR_ARG;
     if (n == 0 || hw == 0) return SPICE_OK;
@@ -323,7 +323,9 @@ extern "C" int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void 
     if (r_mean != nullptr && (residual == nullptr || r_var == nullptr || r_weight == nullptr || r_bias == nullptr))
         return SPICE_ERR_ARG;
     // 16-byte pieces of whole rows of X, R and Y: the plane size must be a multiple of 8 halfs
-    if ((hw & 7) != 0 || !aligned16(x) || !aligned16(y) || (residual != nullptr && !aligned16(residual)))
+    if (y_image_stride == 0) y_image_stride = cout * hw;   // dense
+    if (y_image_stride < cout * hw) return SPICE_ERR_ARG;
+    if ((hw & 7) != 0 || (y_image_stride & 7) != 0 || !aligned16(x) || !aligned16(y) || (residual != nullptr && !aligned16(residual)))
         return SPICE_ERR_UNSUPPORTED;
     if (cin > (1 << 20) || cout > (1 << 20) || hw > (1 << 28)) return SPICE_ERR_UNSUPPORTED;
     const int64_t tiles_n = ceil_div(hw, kMmBN);
@@ -338,6 +340,7 @@ extern "C" int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void 
     a.x = static_cast<const _Float16 *>(x);
     a.w = static_cast<const _Float16 *>(weight);
     a.y = static_cast<_Float16 *>(y);
+    a.y_image_stride = y_image_stride;
     a.res = static_cast<const _Float16 *>(residual);
     a.mean = mean;
     a.var = var;

@@ -268,19 +268,42 @@ int32_t act_code(const Tensor &t, const char *name) {
     return 1;
 }
 
+// `out`, where a kernel of the forward accepts one: a channel slice of a larger NCHW tensor (a concatenation
+// buffer): [n, c, h, w] whose images are whole contiguous blocks, any distance apart.
+void check_slice_out(const Tensor &out, const Tensor &like, int64_t n, int64_t c, int64_t h, int64_t w,
+                     at::ScalarType dtype, const char *name) {
+    TORCH_CHECK(out.device() == like.device(), name, ": out is on ", out.device(), ", expected ", like.device());
+    TORCH_CHECK_TYPE(out.scalar_type() == dtype, name, ": out must be ", dtype, ", got ", out.scalar_type());
+    TORCH_CHECK_VALUE(out.dim() == 4 && out.size(0) == n && out.size(1) == c && out.size(2) == h && out.size(3) == w,
+                      name, ": out must be [", n, ", ", c, ", ", h, ", ", w, "]");
+    TORCH_CHECK_VALUE(out.numel() == 0 || (out.stride(3) == 1 && out.stride(2) == w && out.stride(1) == h * w &&
+                                           (n == 1 || out.stride(0) >= c * h * w)),
+                      name, ": the images of out must be contiguous blocks (a channel slice of an NCHW tensor)");
+}
+
 Tensor upsample_bilinear(const Tensor &x, int64_t out_h, int64_t out_w, bool align_corners, double scale_h,
-                         double scale_w, int64_t out_dtype) {
+                         double scale_w, int64_t out_dtype, const c10::optional<Tensor> &out_opt) {
     const int32_t in_code = act_code(x, "upsample_bilinear");
     check_dev(x, "x", x.scalar_type());
     TORCH_CHECK_VALUE(x.dim() == 4, "upsample_bilinear: x must be [N, C, H, W]");
     TORCH_CHECK_TYPE(out_dtype == 0 || out_dtype == 1, "upsample_bilinear: output dtype code ", out_dtype,
                      " not supported");
+    const at::ScalarType dt = out_dtype == 0 ? at::kFloat : at::kHalf;
     c10::DeviceGuard guard(x.device());
-    Tensor out = at::empty({x.size(0), x.size(1), out_h, out_w}, x.options().dtype(out_dtype == 0 ? at::kFloat : at::kHalf));
-    check_rc(spice_upsample_bilinear(x.data_ptr(), in_code, out.data_ptr(), (int32_t)out_dtype, x.size(0) * x.size(1),
-                                     (int32_t)x.size(2), (int32_t)x.size(3), (int32_t)out_h, (int32_t)out_w,
-                                     align_corners ? 1 : 0, (float)scale_h, (float)scale_w, current_stream(x)),
-             "spice_upsample_bilinear");
+    Tensor out;
+    if (out_opt.has_value()) {
+        out = *out_opt;
+        check_slice_out(out, x, x.size(0), x.size(1), out_h, out_w, dt, "upsample_bilinear");
+    } else {
+        out = at::empty({x.size(0), x.size(1), out_h, out_w}, x.options().dtype(dt));
+    }
+    if (x.numel() == 0) return out;
+    const int64_t group_stride = x.size(0) > 1 ? out.stride(0) : 0;   // the images of out: dense or a slice's
+    check_rc(spice_upsample_bilinear_into(x.data_ptr(), in_code, out.data_ptr(), (int32_t)out_dtype, x.size(0) * x.size(1),
+                                          (int32_t)x.size(2), (int32_t)x.size(3), (int32_t)out_h, (int32_t)out_w,
+                                          align_corners ? 1 : 0, (float)scale_h, (float)scale_w, x.size(1), group_stride,
+                                          current_stream(x)),
+             "spice_upsample_bilinear_into");
     return out;
 }
 
@@ -413,7 +436,7 @@ Tensor conv1x1_f16(const Tensor &x, const Tensor &weight2d) {
     if (cin <= 256 && fused_conv1x1_enabled()) {
         const int frc = spice_conv1x1_bn_act_f16(x.data_ptr(), weight2d.data_ptr(), out.data_ptr(), n, cin, h * w, cout,
                                                  nullptr, nullptr, nullptr, nullptr, 0.0f, nullptr, nullptr, nullptr, nullptr,
-                                                 nullptr, 0.0f, 0, current_stream(x));
+                                                 nullptr, 0.0f, 0, 0, current_stream(x));
         if (frc != SPICE_ERR_UNSUPPORTED) {
             check_rc(frc, "spice_conv1x1_bn_act_f16 (plain product)");
             return out;
@@ -436,7 +459,7 @@ Tensor conv1x1_bn_act(const Tensor &x, const Tensor &weight2d, const Tensor &mea
                       const Tensor &weight, const Tensor &bias, double eps, const c10::optional<Tensor> &residual,
                       const c10::optional<Tensor> &r_mean, const c10::optional<Tensor> &r_var,
                       const c10::optional<Tensor> &r_weight, const c10::optional<Tensor> &r_bias, double r_eps, bool relu,
-                      int64_t route) {
+                      int64_t route, const c10::optional<Tensor> &out_opt) {
     TORCH_CHECK_VALUE(route >= 0 && route <= 2, "conv1x1_bn_act: route must be 0 (choose), 1 (one launch) or 2 (two launches)");
     TORCH_CHECK_TYPE(x.scalar_type() == at::kHalf && weight2d.scalar_type() == at::kHalf,
                      "conv1x1_bn_act: x and weight must be fp16");
@@ -474,12 +497,16 @@ Tensor conv1x1_bn_act(const Tensor &x, const Tensor &weight2d, const Tensor &mea
         rb = r_bias->data_ptr<float>();
     }
     c10::DeviceGuard guard(x.device());
+    if (out_opt.has_value()) check_slice_out(*out_opt, x, n, c, h, w, at::kHalf, "conv1x1_bn_act");
     if (route == 1 || (route == 0 && fused_conv1x1_enabled())) {
-        Tensor out = at::empty({n, c, h, w}, x.options());
-        const int rc = spice_conv1x1_bn_act_f16(x.data_ptr(), weight2d.data_ptr(), out.data_ptr(), n, cin, h * w, c,
-                                                mean.data_ptr<float>(), var.data_ptr<float>(), weight.data_ptr<float>(),
-                                                bias.data_ptr<float>(), (float)eps, res, rm, rv, rw, rb, (float)r_eps,
-                                                relu ? 1 : 0, current_stream(x));
+        Tensor out = out_opt.has_value() ? *out_opt : at::empty({n, c, h, w}, x.options());
+        const int64_t image_stride = out_opt.has_value() && n > 1 ? out.stride(0) : 0;
+        const int rc = n == 0 ? SPICE_OK
+                              : spice_conv1x1_bn_act_f16(x.data_ptr(), weight2d.data_ptr(), out.data_ptr(), n, cin, h * w, c,
+                                                         mean.data_ptr<float>(), var.data_ptr<float>(),
+                                                         weight.data_ptr<float>(), bias.data_ptr<float>(), (float)eps, res, rm,
+                                                         rv, rw, rb, (float)r_eps, relu ? 1 : 0, image_stride,
+                                                         current_stream(x));
         if (rc != SPICE_ERR_UNSUPPORTED || route == 1) {
             check_rc(rc, "spice_conv1x1_bn_act_f16");
             return out;
@@ -498,6 +525,10 @@ Tensor conv1x1_bn_act(const Tensor &x, const Tensor &weight2d, const Tensor &mea
                           relu ? 1 : 0, current_stream(t));
     }
     check_rc(rc, "spice_bn_act (behind conv1x1)");
+    if (out_opt.has_value()) {   // the two-launch route writes a dense tensor: one more pass into the slice
+        out_opt->copy_(t);
+        return *out_opt;
+    }
     return t;
 }
 
@@ -524,7 +555,7 @@ TORCH_LIBRARY(spice, m) {
           "float coef_ce, float coef_kd, Tensor? upstream, Tensor(a!) workspace) -> (Tensor, Tensor)", &kdlite_forward);
     m.def("scale_inplace(Tensor(a!) x, Tensor scale) -> ()", &scale_inplace);
     m.def("upsample_bilinear(Tensor x, int out_h, int out_w, bool align_corners, float scale_h, float scale_w, "
-          "int out_dtype) -> Tensor", &upsample_bilinear);
+          "int out_dtype, Tensor(a!)? out) -> Tensor(a!)", &upsample_bilinear);
     m.def("bn_act(Tensor x, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, Tensor? residual, "
           "bool relu) -> Tensor", &bn_act);
     m.def("bn_act_dual(Tensor x, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, Tensor residual, "
@@ -535,5 +566,5 @@ TORCH_LIBRARY(spice, m) {
     m.def("conv1x1_f16(Tensor x, Tensor weight2d) -> Tensor", &conv1x1_f16);
     m.def("conv1x1_bn_act(Tensor x, Tensor weight2d, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, "
           "Tensor? residual, Tensor? r_mean, Tensor? r_var, Tensor? r_weight, Tensor? r_bias, float r_eps, bool relu, "
-          "int route) -> Tensor", &conv1x1_bn_act);
+          "int route, Tensor(a!)? out) -> Tensor(a!)", &conv1x1_bn_act);
 }

@@ -33,6 +33,8 @@ struct UpArgs {
     int align_corners;
     float scale_h, scale_w;
     float inv_per_row;    // 1 / (lane work items per output row)
+    int planes_per_group;        // destination: planes of a group lie one behind the other,
+    int64_t dst_group_stride;    // groups this many elements apart (a channel slice of a larger tensor)
 };
 
 __device__ __forceinline__ float src_index(float scale, int dst, int align_corners) {
@@ -94,7 +96,9 @@ __global__ __launch_bounds__(kUpThreads) void upsample_bilinear_kernel(UpArgs a)
     }
     __syncthreads();
 
-    TOut *dp = static_cast<TOut *>(a.dst) + (static_cast<int64_t>(plane) * a.out_h + oy0) * a.out_w;
+    const int group = plane / a.planes_per_group;
+    TOut *dp = static_cast<TOut *>(a.dst) + group * a.dst_group_stride +
+               (static_cast<int64_t>(plane - group * a.planes_per_group) * a.out_h + oy0) * a.out_w;
     for (int q = threadIdx.x; q < n_rows * per_row; q += kUpThreads) {
         const int ry = static_cast<int>((static_cast<float>(q) + 0.5f) * a.inv_per_row);
         const int ox = (q - ry * per_row) * VEC;
@@ -161,10 +165,22 @@ extern "C" int spice_upsample_bilinear(const void *src, int32_t src_dtype, void 
                                        int64_t planes, int32_t in_h, int32_t in_w, int32_t out_h,
                                        int32_t out_w, int32_t align_corners, float scale_h, float scale_w,
                                        void *stream) {
+    return spice_upsample_bilinear_into(src, src_dtype, dst, dst_dtype, planes, in_h, in_w, out_h, out_w, align_corners,
+                                        scale_h, scale_w, planes > 0 ? planes : 1, 0, stream);
+}
+
+extern "C" int spice_upsample_bilinear_into(const void *src, int32_t src_dtype, void *dst, int32_t dst_dtype,
+                                            int64_t planes, int32_t in_h, int32_t in_w, int32_t out_h,
+                                            int32_t out_w, int32_t align_corners, float scale_h, float scale_w,
+                                            int64_t planes_per_group, int64_t dst_group_stride, void *stream) {
     using namespace spice;
     if (planes < 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0) return SPICE_ERR_ARG;
     if (planes == 0) return SPICE_OK;
     if (src == nullptr || dst == nullptr) return SPICE_ERR_ARG;
+    if (planes_per_group < 1 || planes_per_group > INT32_MAX || planes % planes_per_group != 0) return SPICE_ERR_ARG;
+    // groups must not overlap (one group needs no stride)
+    if (planes > planes_per_group && dst_group_stride < planes_per_group * static_cast<int64_t>(out_h) * out_w)
+        return SPICE_ERR_ARG;
     if ((src_dtype != 0 && src_dtype != 1) || (dst_dtype != 0 && dst_dtype != 1)) return SPICE_ERR_UNSUPPORTED;
     if (out_h < in_h || out_w < in_w) return SPICE_ERR_UNSUPPORTED;   // up-sampling only
     UpArgs a;
@@ -175,6 +191,8 @@ extern "C" int spice_upsample_bilinear(const void *src, int32_t src_dtype, void 
     a.out_h = out_h;
     a.out_w = out_w;
     a.align_corners = align_corners ? 1 : 0;
+    a.planes_per_group = static_cast<int>(planes_per_group);
+    a.dst_group_stride = dst_group_stride;
     // torch's area_pixel_compute_scale: (in-1)/(out-1) with aligned corners (0 for one output),
     // otherwise 1/scale_factor when the caller passed one (> 0 here) or in/out
     if (a.align_corners) {
@@ -197,7 +215,7 @@ extern "C" int spice_upsample_bilinear(const void *src, int32_t src_dtype, void 
     a.lds_rows = static_cast<int>(static_cast<float>(a.rows_per_block - 1) * a.scale_h) + 4;
     if (a.lds_rows > in_h) a.lds_rows = in_h;
     const size_t out_elem = dst_dtype == 0 ? 4 : 2;
-    const bool vec = out_w % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) % (4 * out_elem)) == 0;
+    const bool vec = out_w % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) % (4 * out_elem)) == 0 && dst_group_stride % 4 == 0;
     a.inv_per_row = 1.0f / static_cast<float>(vec ? out_w / 4 : out_w);
     // the float reciprocal splits a work-item number into (row, column) exactly while the numbers
     // stay far below 2^22

@@ -36,19 +36,24 @@ class BilinearUp(nn.UpsamplingBilinear2d):
         super().__init__(scale_factor=scale_factor)
         self.follow_input_dtype = follow_input_dtype
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """`out`: where to write the result (a channel slice of a concatenation buffer; the kernel writes there
+        directly, the torch path copies)."""
         wants_grad = torch.is_grad_enabled() and x.requires_grad
         # fp16 input is taken under autocast only, where torch would first cast it to fp32: torch's own fp16
         # kernel rounds its last multiply-add and the conversion in one step, which differs on ties
         if (not layers.library_forward() or not x.is_cuda or wants_grad or x.dim() != 4
                 or not (x.dtype == torch.float32 or (x.dtype == torch.float16 and torch.is_autocast_enabled("cuda")))):
-            return super().forward(x)
+            return layers._into(out, super().forward(x))
         from .. import ops
         out_dtype = x.dtype
         if torch.is_autocast_enabled("cuda") and not self.follow_input_dtype:
             out_dtype = torch.float32
+        if out is not None and out.dtype != out_dtype:
+            return layers._into(out, ops.upsample_bilinear(x.contiguous(), scale_factor=float(self.scale_factor),
+                                                           align_corners=True, out_dtype=out_dtype))
         return ops.upsample_bilinear(x.contiguous(), scale_factor=float(self.scale_factor), align_corners=True,
-                                     out_dtype=out_dtype)
+                                     out_dtype=out_dtype, out=out)
 
 
 class BilinearLike(nn.Upsample):
@@ -60,14 +65,24 @@ class BilinearLike(nn.Upsample):
     def __init__(self):
         super().__init__(mode="bilinear", align_corners=False)
 
-    def forward(self, y, like):
+    def forward(self, y, like, out=None):
         size = tuple(like.shape[-2:])
         wants_grad = torch.is_grad_enabled() and y.requires_grad
         if (not layers.library_forward() or not y.is_cuda or wants_grad or y.dim() != 4
                 or not (y.dtype == torch.float32 or (y.dtype == torch.float16 and torch.is_autocast_enabled("cuda")))):
-            return F.interpolate(y, size=size, mode="bilinear", align_corners=False)
+            return layers._into(out, F.interpolate(y, size=size, mode="bilinear", align_corners=False))
         from .. import ops
-        return ops.upsample_bilinear(y.contiguous(), size=size, align_corners=False)
+        if out is not None and out.dtype != y.dtype:
+            return layers._into(out, ops.upsample_bilinear(y.contiguous(), size=size, align_corners=False))
+        return ops.upsample_bilinear(y.contiguous(), size=size, align_corners=False, out=out)
+
+
+def _writes_in_place(x) -> bool:
+    """Whether the producers of a concatenation may write their slices of it directly: real tensors on a HIP
+    device, inference, fp16 autocast (every producer's result is fp16 there, as the consumer convolution's cast of
+    the concatenation would make it)."""
+    return (isinstance(x, torch.Tensor) and layers.library_forward() and x.is_cuda and not torch.is_grad_enabled()
+            and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16)
 
 
 def _conv_bn_relu(conv: nn.Module, ch: int) -> nn.Sequential:
@@ -83,8 +98,9 @@ class ASPPPooling(nn.Module):
         self.relu = nn.ReLU()
         self.up = BilinearLike()
 
-    def forward(self, x):
-        return self.up(self.relu(self.bn(self.conv(self.pool(x)))), x)
+    def forward(self, x, out=None):
+        y = self.relu(self.bn(self.conv(self.pool(x))))
+        return self.up(y, x) if out is None else self.up(y, x, out=out)
 
 
 class ASPP(nn.Module):
@@ -101,7 +117,17 @@ class ASPP(nn.Module):
                                      BatchNormAct2d(out_ch, relu=True), nn.Dropout(0.5))
 
     def forward(self, x):
-        y = torch.cat([b(x) for b in self.convs], dim=1)
+        if _writes_in_place(x):
+            # every branch writes its channels of the concatenation itself: no concatenation pass
+            n, _, h, w = x.shape
+            widths = [b[1].num_features if isinstance(b, ConvBnAct) else b.bn.num_features for b in self.convs]
+            y = torch.empty(n, sum(widths), h, w, device=x.device, dtype=torch.float16)
+            at = 0
+            for b, c in zip(self.convs, widths):
+                b(x, out=y[:, at:at + c])
+                at += c
+        else:
+            y = torch.cat([b(x) for b in self.convs], dim=1)
         return self.project[2](conv1x1_bn(self.project[0], self.project[1], y))
 
 
@@ -124,10 +150,20 @@ class DeepLabV3PlusDecoder(nn.Module):
 
     def forward(self, features: List[torch.Tensor]):
         a = self.aspp   # ASPP -> separable 3x3 (depthwise, pointwise) -> batch-norm + ReLU
-        deep = self.up(conv1x1_bn(a[1][1], a[2], a[1][0](a[0](features[-1]))) if type(a[1][1]) is Conv1x1
-                       else a(features[-1]))
-        high = self.block1(features[2])
-        return self.block2(torch.cat([deep, high], dim=1))
+        deep = (conv1x1_bn(a[1][1], a[2], a[1][0](a[0](features[-1]))) if type(a[1][1]) is Conv1x1
+                else a(features[-1]))
+        skip = features[2]
+        s = int(self.up.scale_factor)
+        if (_writes_in_place(skip) and self.up.scale_factor == s and deep.dim() == 4
+                and (deep.shape[2] * s, deep.shape[3] * s) == tuple(skip.shape[2:])):
+            # both producers write their channels of the concatenation themselves: no concatenation pass
+            c_deep, c_high = deep.shape[1], self.block1[1].num_features
+            both = torch.empty(skip.shape[0], c_deep + c_high, skip.shape[2], skip.shape[3], device=skip.device,
+                               dtype=torch.float16)
+            self.up(deep, out=both[:, :c_deep])
+            self.block1(skip, out=both[:, c_deep:])
+            return self.block2(both)
+        return self.block2(torch.cat([self.up(deep), self.block1(skip)], dim=1))
 
 
 class UnetDecoderBlock(nn.Module):

@@ -141,12 +141,22 @@ def _hooked(m: nn.Module) -> bool:
     return bool(m._forward_hooks or m._forward_pre_hooks)
 
 
-def conv1x1_bn(conv: Conv1x1, bn: BatchNormAct2d, x, residual=None, residual_norm: Optional[nn.BatchNorm2d] = None):
+def _into(out, y):
+    """`y` written into `out` when one was given (a channel slice of a concatenation buffer)."""
+    if out is None:
+        return y
+    out.copy_(y)
+    return out
+
+
+def conv1x1_bn(conv: Conv1x1, bn: BatchNormAct2d, x, residual=None, residual_norm: Optional[nn.BatchNorm2d] = None,
+               out: Optional[torch.Tensor] = None):
     """bn(conv(x) [, residual [, residual_norm]]).  On the inference path of a HIP device, where `conv` is the
-    library's matrix product and `bn` the library's fused tail, the pair is ONE call of the extension (two launches,
-    the product normalised in place) instead of two module calls: the Python around a launch costs more than the
-    launch once the device work of a forward is a few milliseconds.  Modules carrying forward hooks, symbolic
-    tracing, training and every other situation take the modules one after the other."""
+    library's matrix product and `bn` the library's fused tail, the pair is ONE call of the extension (one launch of
+    the matrix-core kernel that normalises the product before storing it; two launches where that kernel does not
+    take the shapes) instead of two module calls.  Modules carrying forward hooks, symbolic tracing, training and
+    every other situation take the modules one after the other.  `out`: where to write the result (a channel slice
+    of a concatenation buffer); the one-launch route writes there directly, every other route copies."""
     if (isinstance(x, torch.Tensor) and _LIBRARY_FORWARD and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4
             and not torch.nn.modules.module._global_forward_hooks
             and not (_hooked(conv) or _hooked(bn)) and conv.takes_matrix_path(x.dtype) and _plain_inference_norm(bn)
@@ -157,16 +167,18 @@ def conv1x1_bn(conv: Conv1x1, bn: BatchNormAct2d, x, residual=None, residual_nor
         if residual_norm is not None:
             ok = ok and residual is not None and _plain_inference_norm(residual_norm) and not _hooked(residual_norm) \
                 and residual_norm.num_features == bn.num_features
+        if out is not None:
+            ok = ok and out.dtype == torch.float16
         if ok:
             if x.dtype != torch.float16:
                 x = x.to(torch.float16)   # what autocast does to a convolution's input
             if x.is_contiguous():
-                return ops.conv1x1_bn_act(x, _fp16_matrix(conv.weight), bn, residual, residual_norm, bn.relu_after)
+                return ops.conv1x1_bn_act(x, _fp16_matrix(conv.weight), bn, residual, residual_norm, bn.relu_after, out=out)
     if residual is None:
-        return bn(conv(x))
+        return _into(out, bn(conv(x)))
     if residual_norm is None:
-        return bn(conv(x), residual)
-    return bn(conv(x), residual, residual_norm)
+        return _into(out, bn(conv(x), residual))
+    return _into(out, bn(conv(x), residual, residual_norm))
 
 
 class ConvBnAct(nn.Sequential):
@@ -175,10 +187,10 @@ class ConvBnAct(nn.Sequential):
     def __init__(self, conv: nn.Module, bn: BatchNormAct2d):
         super().__init__(conv, bn)
 
-    def forward(self, x):
+    def forward(self, x, out: Optional[torch.Tensor] = None):
         conv = self[0]
         if type(conv) is Conv1x1:
-            return conv1x1_bn(conv, self[1], x)
+            return conv1x1_bn(conv, self[1], x, out=out)
         if isinstance(conv, nn.Sequential) and len(conv) == 2 and type(conv[1]) is Conv1x1:
-            return conv1x1_bn(conv[1], self[1], conv[0](x))   # separable: depthwise, then the pointwise pair
-        return self[1](conv(x))
+            return conv1x1_bn(conv[1], self[1], conv[0](x), out=out)   # separable: depthwise, then the pointwise pair
+        return _into(out, self[1](conv(x)))

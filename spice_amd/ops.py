@@ -382,10 +382,11 @@ def gather_channels(src: torch.Tensor, keep_out: Optional[torch.Tensor],
 
 def upsample_bilinear(x: torch.Tensor, size: Optional[Tuple[int, int]] = None,
                       scale_factor: Optional[float] = None, align_corners: bool = False,
-                      out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+                      out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """F.interpolate(x, size / scale_factor, mode="bilinear", align_corners) for an NCHW device
-    tensor (fp32 or fp16), interpolated in fp32 and written as `out_dtype` (default: x's dtype).
-    Forward only; up-sampling only."""
+    tensor (fp32 or fp16), interpolated in fp32 and written as `out_dtype` (default: x's dtype, or out's).
+    `out`: write into this tensor instead of a new one; it may be a channel slice of a larger NCHW tensor
+    (a concatenation buffer).  Forward only; up-sampling only."""
     if x.dtype not in (torch.float32, torch.float16):
         raise TypeError(f"upsample_bilinear: dtype {x.dtype} not supported")
     nat.require_device_tensor(x, "x", x.dtype)
@@ -400,10 +401,10 @@ def upsample_bilinear(x: torch.Tensor, size: Optional[Tuple[int, int]] = None,
     else:
         sh = sw = float(scale_factor)
         oh, ow = int(h * sh), int(w * sw)   # floor, as torch
-    out_dtype = out_dtype or x.dtype
+    out_dtype = out_dtype or (out.dtype if out is not None else x.dtype)
     if out_dtype not in (torch.float32, torch.float16):
         raise TypeError(f"upsample_bilinear: output dtype {out_dtype} not supported")
-    return spice_ops().upsample_bilinear(x, oh, ow, bool(align_corners), sh, sw, _DTYPE_CODE[out_dtype])
+    return spice_ops().upsample_bilinear(x, oh, ow, bool(align_corners), sh, sw, _DTYPE_CODE[out_dtype], out)
 
 
 def bn_act_supported(x: torch.Tensor) -> bool:
@@ -489,16 +490,17 @@ _conv1x1_bn_fn = None
 
 def conv1x1_bn_act(x: torch.Tensor, weight2d: torch.Tensor, bn: "torch.nn.BatchNorm2d",
                    residual: Optional[torch.Tensor] = None, res_bn: Optional["torch.nn.BatchNorm2d"] = None,
-                   relu: bool = False, route: int = 0) -> torch.Tensor:
+                   relu: bool = False, route: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """relu?(bn(weight2d @ x) [+ residual | + res_bn(residual)]) from one call of the extension.  route 0: the
     matrix-core kernel that applies the tail to the product before storing it (ONE launch) where it takes the shapes
     (plane size a multiple of 8), else conv1x1_f16 followed by the batch-norm tail in place (two launches);
-    route 1 / 2: that kernel / the two launches, explicitly."""
+    route 1 / 2: that kernel / the two launches, explicitly.  `out`: write into this tensor, which may be a channel
+    slice of a larger NCHW tensor (a concatenation buffer), instead of a new one."""
     global _conv1x1_bn_fn
     if _conv1x1_bn_fn is None:
         _conv1x1_bn_fn = spice_ops().conv1x1_bn_act
     if res_bn is None:
         return _conv1x1_bn_fn(x, weight2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, residual,
-                              None, None, None, None, 0.0, relu, route)
+                              None, None, None, None, 0.0, relu, route, out)
     return _conv1x1_bn_fn(x, weight2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, residual,
-                          res_bn.running_mean, res_bn.running_var, res_bn.weight, res_bn.bias, res_bn.eps, relu, route)
+                          res_bn.running_mean, res_bn.running_var, res_bn.weight, res_bn.bias, res_bn.eps, relu, route, out)

@@ -61,7 +61,7 @@ def test_fused_plain_product_is_exact_on_integer_data(dev, shape):
     guard = torch.full((4096,), 7.0, dtype=torch.float16, device=dev)   # allocated right behind y: must stay untouched
     null = ctypes.c_void_p(0)
     rc = nat.lib().spice_conv1x1_bn_act_f16(x.data_ptr(), wt.data_ptr(), y.data_ptr(), n, cin, h * w, cout, null, null,
-                                            null, null, 0.0, null, null, null, null, null, 0.0, 0,
+                                            null, null, 0.0, null, null, null, null, null, 0.0, 0, 0,
                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     torch.cuda.synchronize()
@@ -131,3 +131,24 @@ def test_fused_rejects_what_it_cannot_take(dev):
         with pytest.raises(ValueError):
             ops.conv1x1_bn_act(x, wt, bn, None, None, True, route=5)
         assert ops.conv1x1_bn_act(x[:0], wt, bn, None, None, True).shape == (0, 4, 2, 3)
+
+
+@pytest.mark.parametrize("route", [1, 2])
+def test_fused_writes_into_a_channel_slice(dev, route):
+    """out= a channel slice of a concatenation buffer: the slice holds what a separate tensor would, its neighbours stay."""
+    shape = (3, 40, 8, 24, 50)
+    n, cin, h, w, cout = shape
+    g, x, wt, _ = _integer_case(shape, dev)
+    bn = _norm(cout, g, dev)
+    res = torch.randn(n, cout, h, w, generator=g).half().to(dev)
+    both = torch.full((n, 16 + cout + 24, h, w), 3.0, dtype=torch.float16, device=dev)
+    with torch.no_grad():
+        want = ops.conv1x1_bn_act(x, wt, bn, res, None, True, route=route)
+        got = ops.conv1x1_bn_act(x, wt, bn, res, None, True, route=route, out=both[:, 16:16 + cout])
+    assert got.data_ptr() == both[:, 16:16 + cout].data_ptr()
+    assert torch.equal(both[:, 16:16 + cout], want)
+    assert bool((both[:, :16] == 3.0).all()) and bool((both[:, 16 + cout:] == 3.0).all())
+    with torch.no_grad(), pytest.raises(ValueError):
+        ops.conv1x1_bn_act(x, wt, bn, res, None, True, out=both[:, :cout, :, ::2])
+    with torch.no_grad(), pytest.raises(TypeError):
+        ops.conv1x1_bn_act(x, wt, bn, res, None, True, out=both.float()[:, :cout])

@@ -873,3 +873,41 @@ def test_resnet_stem_uses_one_launch_and_equals_the_modules(dev):
         enc.skip_stem_feature = True
         none, pooled2 = enc._stem(x)
     assert none is None and torch.equal(pooled, gp) and torch.equal(f1, g1) and torch.equal(pooled2, gp)
+
+
+@pytest.mark.parametrize("dtype,out_dtype,align", [(torch.float16, torch.float16, True), (torch.float32, torch.float32, False),
+                                                    (torch.float16, torch.float32, True)])
+def test_upsample_into_a_channel_slice(dev, dtype, out_dtype, align):
+    """out= a channel slice of a larger tensor: same values as a separate tensor, neighbours untouched."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 10, 6, 8, generator=g).to(dtype).to(dev)
+    both = torch.full((3, 4 + 10 + 6, 24, 32), 3.0, dtype=out_dtype, device=dev)
+    want = ops.upsample_bilinear(x, scale_factor=4.0, align_corners=align, out_dtype=out_dtype)
+    got = ops.upsample_bilinear(x, scale_factor=4.0, align_corners=align, out=both[:, 4:14])
+    assert got.data_ptr() == both[:, 4:14].data_ptr() and torch.equal(both[:, 4:14], want)
+    assert bool((both[:, :4] == 3.0).all()) and bool((both[:, 14:] == 3.0).all())
+    with pytest.raises(ValueError):
+        ops.upsample_bilinear(x, scale_factor=4.0, align_corners=align, out=both[:, 4:14, ::2])
+
+
+def test_deeplab_decoder_without_concatenation_pass(dev):
+    """Producers writing their slices of the concatenations directly give the logits of the forward that concatenates
+    (forced here by a forward hook on the model, which sends every pair through its modules)."""
+    from spice_amd import nets
+    torch.manual_seed(9)
+    model = nets.create_model("DeepLabV3Plus", "resnet50", 7).to(dev).eval()
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0.0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(2, 3, 128, 160, device=dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        direct = model(x)
+        from spice_amd.nets import decoders
+        keep = decoders._writes_in_place
+        decoders._writes_in_place = lambda t: False
+        try:
+            concatenated = model(x)
+        finally:
+            decoders._writes_in_place = keep
+    assert torch.equal(direct, concatenated)

@@ -252,6 +252,50 @@ def main():
                                                       for a, r in zip(xs, rs)], args.iters), 3 * nb)
         outs.clear()
 
+    if "conv1x1" in only or "conv1x1_pmc" in only:   # opt-in: one kernel name at several sizes
+        # the one-launch 1x1 convolution + batch-norm tail at four pairs of the DeepLabV3+-R50 forward (batch 8, 512x512 input):
+        # algorithmic bytes = x + y (+ residual), fp16; the weights (<= 0.5 MB) are not counted
+        for name, cin, cout, side, res in (("layer1 conv3 + residual", 64, 256, 128, True), ("layer1 conv1", 256, 64, 128, False),
+                                           ("layer2 conv3 + residual", 128, 512, 64, True), ("layer3 conv1", 1024, 256, 32, False)):
+            if "conv1x1_pmc" in only and not name.startswith("layer1 conv3"):
+                continue   # one size per counter pass: the counters are summed per kernel name
+            n_buf = 4
+            xs = [torch.randn(8, cin, side, side, device=dev).half() for _ in range(n_buf)]
+            rs = [torch.randn(8, cout, side, side, device=dev).half() for _ in range(n_buf)] if res else [None] * n_buf
+            w = (torch.randn(cout, cin, device=dev) / cin ** 0.5).half()
+            bn = torch.nn.BatchNorm2d(cout).eval().to(dev)
+            nb = 2 * 8 * side * side * (cin + cout + (cout if res else 0))
+            outs = []
+            keep = lambda t: outs.append(t) or (len(outs) > 2 and outs.pop(0))
+            with torch.no_grad():
+                report(f"conv1x1_bn_act one launch, {name} {cin}->{cout} @{side}x{side}",
+                       timed([lambda a=a, r=r: keep(ops.conv1x1_bn_act(a, w, bn, r, None, True, route=1)) for a, r in zip(xs, rs)],
+                             args.iters), nb)
+                if "conv1x1" in only:
+                    report(f"conv1x1_bn_act two launches, {name} {cin}->{cout} @{side}x{side}",
+                           timed([lambda a=a, r=r: keep(ops.conv1x1_bn_act(a, w, bn, r, None, True, route=2)) for a, r in zip(xs, rs)],
+                                 args.iters), nb)
+            outs.clear()
+
+    if "stem" in only:
+        # ResNet stem behind the first convolution: [8, 64, 256, 256] fp16 -> pooled [8, 64, 128, 128] (the first
+        # feature map not stored, as in the DeepLabV3+ model); algorithmic bytes = x + pooled
+        import torch.nn.functional as F
+        shp = (8, 64, 256, 256)
+        xs = [torch.randn(*shp, device=dev).half() for _ in range(5)]
+        bn = torch.nn.BatchNorm2d(64).eval().to(dev)
+        nb = xs[0].numel() * 2 * 5 // 4
+        outs = []
+        keep = lambda t: outs.append(t) or (len(outs) > 2 and outs.pop(0))
+        with torch.no_grad():
+            report("bn_act_maxpool (pooled only)", timed([lambda a=a: keep(ops.bn_act_maxpool(a, bn, want_full=False)[1]) for a in xs],
+                                                         args.iters), nb)
+            if "conv1x1_pmc" not in only:
+                report("bn_act + torch max_pool2d", timed([lambda a=a: keep(F.max_pool2d(
+                    ops.bn_act(a, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, relu=True), 3, 2, 1)) for a in xs],
+                    args.iters), nb)
+        outs.clear()
+
 
 if __name__ == "__main__":
     main()

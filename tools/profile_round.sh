@@ -9,11 +9,12 @@ mkdir -p "$OUT"
 # 1. every kernel alone, per-dispatch trace
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kbench" -o kb -- python3 tools/kbench.py --iters 25 > "$OUT/kbench.log" 2>&1
 python3 tools/trace_medians.py "$OUT/kbench" > "$OUT/kbench_medians.txt"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kbench_fwd" -o kb -- python3 tools/kbench.py --only upsample,depthwise,bnact --iters 25 > "$OUT/kbench_fwd.log" 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kbench_fwd" -o kb -- python3 tools/kbench.py --only upsample,depthwise,bnact,conv1x1,stem --iters 25 > "$OUT/kbench_fwd.log" 2>&1
 python3 tools/trace_medians.py "$OUT/kbench_fwd" > "$OUT/kbench_fwd_medians.txt"
 # 2. the bench command itself
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o bench -- python3 bench.py --no-cpu-baseline > "$OUT/bench_line.json" 2> "$OUT/bench.err"
 python3 tools/trace_medians.py "$OUT/bench" > "$OUT/bench_medians.txt"
+python3 tools/stepbreakdown.py "$(find "$OUT/bench" -name "*kernel_trace.csv" | head -1)" > "$OUT/sweep_step_breakdown.txt"
 # 3. HBM traffic: one counter per pass, nothing else traced
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 tools/kbench.py --iters 6 > "$OUT/pmc_fetch.log" 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 tools/kbench.py --iters 6 > "$OUT/pmc_write.log" 2>&1
@@ -21,6 +22,9 @@ python3 tools/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" > "$OUT/pmc_traff
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_small" -- python3 tools/kbench.py --only gather_cols,confusion_small --iters 6 > "$OUT/pmc_fetch_small.log" 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_small" -- python3 tools/kbench.py --only gather_cols,confusion_small --iters 6 > "$OUT/pmc_write_small.log" 2>&1
 python3 tools/pmc_summary.py "$OUT/pmc_fetch_small" "$OUT/pmc_write_small" > "$OUT/pmc_traffic_small_cases.json"
-rm -rf "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_fetch_small "$OUT"/pmc_write_small
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_fwd" -- python3 tools/kbench.py --only conv1x1_pmc,stem --iters 6 > "$OUT/pmc_fetch_fwd.log" 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_fwd" -- python3 tools/kbench.py --only conv1x1_pmc,stem --iters 6 > "$OUT/pmc_write_fwd.log" 2>&1
+python3 tools/pmc_summary.py "$OUT/pmc_fetch_fwd" "$OUT/pmc_write_fwd" > "$OUT/pmc_traffic_forward_kernels.json"
+rm -rf "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_fetch_small "$OUT"/pmc_write_small "$OUT"/pmc_fetch_fwd "$OUT"/pmc_write_fwd
 find "$OUT" -name "*kernel_trace.csv" -size +20M -delete
 echo profile pass done

@@ -192,7 +192,7 @@ def kernel_table(dev):
         event_ms(lambda: ops.bn_act(cyc(acts), bn[0], bn[1], bn[2], bn[3], 1e-5, residual=acts[k[0] % 4 - 1], relu=True), 20),
         acts[0].numel() * 2 * 3)
     wdw = torch.randn(256, 1, 3, 3, device=dev)
-    row("depthwise 3x3 (exact sums), [8,256,128,128] fp16",
+    row("depthwise 3x3, [8,256,128,128] fp16",
         event_ms(lambda: ops.depthwise_conv3x3(cyc(acts), wdw), 20), acts[0].numel() * 2 * 2)
     return out
 

@@ -339,8 +339,11 @@ int spice_bn_act_maxpool_f16(const void *x, void *full, void *pooled, const floa
  * depthwise half of the DeepLabV3+ decoder's separable convolutions, which
  * MIOpen serves with its reference kernel.  x and y are [n, c, h, w] fp16
  * contiguous; weight is [c, 1, 3, 3], fp16 (weight_dtype 1) or fp32 (0: rounded
- * to fp16 first, as autocast's cast does).  Products and sums are exact (fp64),
- * the result is rounded to fp16 once.  w must be a multiple of 8 and <= 2048.
+ * to fp16 first, as autocast's cast does).  The nine products (exact in fp32) are
+ * added to an fp32 sum in tap order, rows first, with fused multiply-adds, and the
+ * result is rounded to fp16 once: the arithmetic of torch's own depthwise kernel
+ * (within one fp16 step of the exact sum MIOpen's reference kernel computes).
+ * w must be a multiple of 8 and <= 2048.
  * ------------------------------------------------------------------------- */
 int spice_depthwise_conv3x3(const void *x, const void *weight, int32_t weight_dtype, void *y,
                             int64_t n, int64_t c, int32_t h, int32_t w, void *stream);

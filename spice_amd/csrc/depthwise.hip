@@ -1,12 +1,16 @@
 // Depthwise 3x3 convolution, stride 1, padding 1, fp16 NCHW: the first half of the separable
 // convolutions of the DeepLabV3+ decoder (the models of pruning/models.py:35-39).  MIOpen runs these
 // shapes on its reference kernel (one thread per output, fp64 accumulation), ten times slower than
-// the memory traffic asks for; this kernel keeps that kernel's arithmetic (every product and the sum
-// of the nine exact in fp64, one rounding to fp16 at the end) and streams the planes.
+// the memory traffic asks for.  This kernel streams the planes and sums as torch's OWN depthwise
+// kernel does (the one torch runs for these calls with MIOpen switched off, and for the dilated
+// calls below in any case): the nine products, exact in fp32, added to an fp32 sum in tap order with
+// fused multiply-adds, one rounding to fp16 at the end.  Within one fp16 step of MIOpen's exact sum.
+// (A first version summed in fp64 to equal MIOpen's kernel bit for bit; the 72 fp64 multiply-adds
+// and conversions per lane made it bound by arithmetic at 2.7 times the time the traffic needs.)
 //
 // HBM-bound: reads the input once (neighbouring rows and the two edge columns of a lane's window
 // come from L1/L2) and writes the output once.  A lane produces 8 consecutive outputs of one row:
-// three 16-byte row loads plus the two neighbours left and right of each, 72 fp64 multiply-adds,
+// three 16-byte row loads plus the two neighbours left and right of each, 72 multiply-adds,
 // one 16-byte store.
 #include "common.h"
 
@@ -40,12 +44,12 @@ __global__ __launch_bounds__(kDwThreads) void depthwise3x3_kernel(DwArgs a) {
     const int yc = min(y, a.h - 1);
     const int x0 = lx * 8;
 
-    double wt[9];
+    float wt[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const _Float16 v = a.w_is_f32 ? static_cast<_Float16>(static_cast<const float *>(a.w)[ch * 9 + k])
                                       : static_cast<const _Float16 *>(a.w)[ch * 9 + k];
-        wt[k] = static_cast<double>(v);
+        wt[k] = static_cast<float>(v);
     }
 
     const _Float16 *src = a.x + static_cast<int64_t>(plane) * a.h * a.wd;
@@ -60,26 +64,32 @@ __global__ __launch_bounds__(kDwThreads) void depthwise3x3_kernel(DwArgs a) {
         left[r] = row[max(x0 - 1, 0)];
         right[r] = row[min(x0 + 8, a.wd - 1)];
     }
-    double acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.0;
+    float v[3][10];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const int yy = yc + r - 1;
         const bool row_in = yy >= 0 && yy < a.h;
-        double v[10];
-        v[0] = row_in && x0 > 0 ? static_cast<double>(left[r]) : 0.0;
+        v[r][0] = row_in && x0 > 0 ? static_cast<float>(left[r]) : 0.0f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e + 1] = row_in ? static_cast<double>(mid[r][e]) : 0.0;
-        v[9] = row_in && x0 + 8 < a.wd ? static_cast<double>(right[r]) : 0.0;
+        for (int e = 0; e < 8; ++e) v[r][e + 1] = row_in ? static_cast<float>(mid[r][e]) : 0.0f;
+        v[r][9] = row_in && x0 + 8 < a.wd ? static_cast<float>(right[r]) : 0.0f;
+    }
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)   // tap order: rows first, left to right (a tap outside the plane adds w * 0)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = __builtin_fma(wt[r * 3 + j], v[e + j], acc[e]);
-    }
+            for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(wt[r * 3 + j], v[r][e + j], acc[e]);
     f16x8_t out;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) out[e] = static_cast<_Float16>(acc[e]);
+    for (int e = 0; e < 8; ++e) {
+        float o = acc[e];
+        asm volatile("" : "+v"(o));   // fp32 sum first, conversion as a step of its own
+        out[e] = static_cast<_Float16>(o);
+    }
     if (active) *reinterpret_cast<f16x8_t *>(a.y + (static_cast<int64_t>(plane) * a.h + y) * a.wd + x0) = out;
 }
 

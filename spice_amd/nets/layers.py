@@ -69,10 +69,10 @@ class BatchNormAct2d(nn.BatchNorm2d):
 class DepthwiseConv3x3(nn.Conv2d):
     """nn.Conv2d(ch, ch, 3, padding=dilation, dilation=dilation, groups=ch, bias=False).  On fp16
     activations (autocast) under no_grad on a HIP device, with dilation 1 or a multiple of 4, the
-    forward is the library's streaming kernel: exact sums and one rounding without dilation (what
-    MIOpen's reference kernel, which serves those shapes, computes), fp32 sums in tap order with
-    dilation (what torch's own depthwise kernel, which serves those, computes).  In every other
-    situation torch's conv2d runs."""
+    forward is the library's streaming kernel: fp32 sums of the nine (exact) products in tap order,
+    one rounding, which is what torch's own depthwise kernel computes (torch serves the dilated
+    calls with it; the plain ones go to MIOpen's reference kernel, whose exact sum is within one
+    fp16 step).  In every other situation torch's conv2d runs."""
 
     def __init__(self, channels: int, dilation: int = 1):
         super().__init__(channels, channels, 3, padding=dilation, dilation=dilation, groups=channels, bias=False)

@@ -467,8 +467,8 @@ def depthwise_conv3x3_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
 
 def depthwise_conv3x3(x: torch.Tensor, weight: torch.Tensor, dilation: int = 1) -> torch.Tensor:
     """conv2d(x, weight, stride=1, padding=dilation, dilation=dilation, groups=C) for fp16 x.
-    dilation 1: exact sums, one rounding; dilation a multiple of 4: fp32 sums in tap order (what
-    torch's own depthwise kernel, which serves those calls, computes)."""
+    fp32 sums of the nine products in tap order, one rounding (what torch's own depthwise kernel computes;
+    dilation 1 or a multiple of 4)."""
     return spice_ops().depthwise_conv3x3(x, weight, int(dilation))
 
 

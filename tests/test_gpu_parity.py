@@ -583,22 +583,26 @@ def test_model_forward_on_library_kernels_equals_torch_forward(dev):
                                             ((2, 304, 36, 40), torch.float32), ((8, 304, 128, 128), torch.float32),
                                             ((1, 2, 1, 8), torch.float16), ((2, 5, 300, 24), torch.float16)])
 def test_depthwise_conv3x3_vs_oracle_and_torch(dev, shape, w_dtype):
-    """Bit for bit against the CPU oracle (exact sums, one rounding); what torch runs on the device
-    for the same call (solver-dependent, fp32 or fp64 accumulation) is within one fp16 step of it
-    on a few elements in ten thousand."""
+    """Bit for bit against the CPU oracle of torch's own depthwise kernel (fp32 sums in tap order, one rounding)
+    and against that kernel itself on the device (torch with MIOpen switched off); within one fp16 step of the
+    exact sum, which is what MIOpen's reference kernel (torch's default route for this call) computes."""
     from oracle import depthwise as od
     g = torch.Generator().manual_seed(sum(shape))
     x = torch.randn(*shape, generator=g).half()
     w = (0.5 * torch.randn(shape[1], 1, 3, 3, generator=g)).to(w_dtype)
     got = ops.depthwise_conv3x3(x.to(dev), w.to(dev))
-    want = od.depthwise_conv3x3(x, w)
-    assert got.dtype == torch.float16 and torch.equal(got.cpu(), want)
-    there = torch.nn.functional.conv2d(x.to(dev), w.to(dev).half(), None, 1, 1, 1, shape[1])
+    assert got.dtype == torch.float16 and torch.equal(got.cpu(), od.depthwise_conv3x3_fp32_chain(x, w, 1))
+    with torch.backends.cudnn.flags(enabled=False):
+        native = torch.nn.functional.conv2d(x.to(dev), w.to(dev).half(), None, 1, 1, 1, shape[1])
+    assert torch.equal(got, native)
+    exact = od.depthwise_conv3x3(x, w)
     # one fp16 step of the result, plus fp32 accumulation error of nine terms where they cancel
     terms = 9.0 * float(x.abs().max()) * float(w.abs().max())
-    step = got.float().abs() * 2.0 ** -10 + terms * 2.0 ** -22
-    assert bool(((there.float() - got.float()).abs() <= step).all())
-    assert int((there != got).sum()) <= max(2, got.numel() // 1000)
+    step = exact.float().abs() * 2.0 ** -10 + terms * 2.0 ** -22
+    assert bool(((got.float().cpu() - exact.float()).abs() <= step).all())
+    assert int((got.cpu() != exact).sum()) <= max(2, got.numel() // 1000)
+    there = torch.nn.functional.conv2d(x.to(dev), w.to(dev).half(), None, 1, 1, 1, shape[1])   # torch's default route
+    assert bool(((there.float() - got.float()).abs() <= step.to(dev)).all())
 
 
 def test_depthwise_conv3x3_rejects_other_layouts(dev):
@@ -891,9 +895,11 @@ def test_upsample_into_a_channel_slice(dev, dtype, out_dtype, align):
 
 
 def test_deeplab_decoder_without_concatenation_pass(dev):
-    """Producers writing their slices of the concatenations directly give the logits of the forward that concatenates
-    (forced here by a forward hook on the model, which sends every pair through its modules)."""
+    """Producers writing their slices of the concatenations directly give what the decoder that concatenates gives,
+    on the same encoder features (whole forwards are not comparable bit for bit: MIOpen may pick another algorithm
+    for a 3x3 convolution from one call to the next)."""
     from spice_amd import nets
+    from spice_amd.nets import decoders
     torch.manual_seed(9)
     model = nets.create_model("DeepLabV3Plus", "resnet50", 7).to(dev).eval()
     for m in model.modules():
@@ -902,12 +908,12 @@ def test_deeplab_decoder_without_concatenation_pass(dev):
             m.running_var.uniform_(0.5, 1.5)
     x = torch.randn(2, 3, 128, 160, device=dev)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-        direct = model(x)
-        from spice_amd.nets import decoders
+        features = model.encoder(x)
+        direct = model.decoder(features)
         keep = decoders._writes_in_place
         decoders._writes_in_place = lambda t: False
         try:
-            concatenated = model(x)
+            concatenated = model.decoder(features)
         finally:
             decoders._writes_in_place = keep
-    assert torch.equal(direct, concatenated)
+    assert direct.dtype == torch.float16 and torch.equal(direct, concatenated)

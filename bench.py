@@ -194,6 +194,20 @@ def kernel_table(dev):
     wdw = torch.randn(256, 1, 3, 3, device=dev)
     row("depthwise 3x3, [8,256,128,128] fp16",
         event_ms(lambda: ops.depthwise_conv3x3(cyc(acts), wdw), 20), acts[0].numel() * 2 * 2)
+    # the matrix-core pair kernel on a bottleneck's last convolution: 64 -> 256 channels on 8x128x128, batch-norm,
+    # residual add and ReLU in the one launch; bytes = x + residual + y (the 32 KB of weights stay in L2)
+    xin = [torch.randn(BATCH, 64, SIZE // 4, SIZE // 4, device=dev).half() for _ in range(4)]
+    w64 = (torch.randn(256, 64, device=dev) / 8.0).half()
+    norm = torch.nn.BatchNorm2d(256).eval().to(dev)
+    with torch.no_grad():
+        row("1x1 convolution 64->256 + batch-norm + residual + ReLU in one launch, [8,.,128,128] fp16",
+            event_ms(lambda: ops.conv1x1_bn_act(cyc(xin), w64, norm, acts[k[0] % 4], None, True, route=1), 20),
+            xin[0].numel() * 2 + acts[0].numel() * 2 * 2)
+        stem_in = [torch.randn(BATCH, 64, SIZE // 2, SIZE // 2, device=dev).half() for _ in range(4)]
+        norm64 = torch.nn.BatchNorm2d(64).eval().to(dev)
+        row("ResNet stem: batch-norm + ReLU + 3x3/2 max-pooling in one launch, [8,64,256,256] fp16",
+            event_ms(lambda: ops.bn_act_maxpool(cyc(stem_in), norm64, want_full=False), 20),
+            stem_in[0].numel() * 2 * 5 // 4)
     return out
 
 

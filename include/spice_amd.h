@@ -388,6 +388,13 @@ int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void *y, int64_t
                              const float *r_var, const float *r_weight, const float *r_bias, float r_eps,
                              int32_t relu, int64_t y_image_stride, void *stream);
 
+/* The plain product for a 1x1 convolution of stride 2 (the projection shortcuts of the ResNet stages that halve the
+ * resolution): y[n][Cout, (h/2)*(w/2)] = weight[Cout, Cin] @ x[n][Cin, even rows, even columns], by the same
+ * matrix-core kernel, which picks the even pixels while it stages x (no strided copy of x, no layout transposes).
+ * h must be even and w a multiple of 16, else SPICE_ERR_UNSUPPORTED. */
+int spice_conv1x1_stride2_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int32_t h,
+                              int32_t w, int64_t cout, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,7 +48,8 @@ struct MmArgs {
     const float *mean, *var, *weight, *bias;           // null mean: no batch-norm, no tail
     const float *r_mean, *r_var, *r_weight, *r_bias;   // batch-norm of the residual, or null
     float eps, r_eps;
-    int M, K, hw;
+    int M, K, hw;           // hw: pixels per image of the PRODUCT
+    int x_hw, x_w, y_w;     // stride 2 only: pixels per image and row width of x, row width of the product
     int tiles_m, tiles_n;   // per image
     unsigned total_tiles;
     int relu;
@@ -101,7 +102,9 @@ __device__ __forceinline__ half2_t bn_tail_pair(half2_t x, half2_t r, const BnCh
     return v;
 }
 
-template <bool A_VEC, int STAGES, int MT>
+// S2: the convolution has stride 2 - the product's pixel (y, x) is x's pixel (2y, 2x): a piece of 8 product pixels
+// is the even elements of 16 consecutive pixels of x (two 16-byte loads).
+template <bool A_VEC, int STAGES, int MT, bool S2 = false>
 __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void conv1x1_bn_act_mfma_kernel(MmArgs a) {
     constexpr int BM = kMmBM * MT;          // channels per workgroup: MT 32-channel product tiles per wave
     constexpr int A_PIECES = 4 * MT;        // 16-byte pieces of A per lane and K step
@@ -127,7 +130,15 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
     const bool has_bn = a.mean != nullptr, has_res = a.res != nullptr, res_bn = a.r_mean != nullptr;
     uint4 rres[ROWS];
 
-    const _Float16 *xi = a.x + img * static_cast<size_t>(a.K) * a.hw;
+    const size_t x_plane = S2 ? static_cast<size_t>(a.x_hw) : static_cast<size_t>(a.hw);
+    const _Float16 *xi = a.x + img * static_cast<size_t>(a.K) * x_plane;
+    // the lane's piece of an X row: pixels n0 + 8 (tid & 7) .. +7 of the product (the same piece in every K step)
+    const int b_p = n0 + (tid & 7) * 8;
+    size_t b_src = static_cast<size_t>(b_p);
+    if constexpr (S2) {
+        const int yo = b_p / a.y_w, xo = b_p - yo * a.y_w;   // a piece lies inside one row: y_w is a multiple of 8
+        b_src = static_cast<size_t>(2 * yo) * a.x_w + 2 * xo;
+    }
 
     // global -> register staging per K step: A_PIECES 16-byte pieces of A and two of B per lane
     uint4 ra_all[STAGES][A_PIECES], rb_all[STAGES][2];
@@ -153,10 +164,18 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = tid + kMmThreads * i;
-            const int kk = k0 + (c >> 3), p = n0 + (c & 7) * 8;
+            const int kk = k0 + (c >> 3);
             rb[i] = make_uint4(0, 0, 0, 0);
-            if (kk < a.K && p < a.hw)   // hw is a multiple of 8: a piece is inside the row or outside it
-                rb[i] = *reinterpret_cast<const uint4 *>(xi + static_cast<size_t>(kk) * a.hw + p);
+            if (kk < a.K && b_p < a.hw) {   // hw is a multiple of 8: a piece is inside the row or outside it
+                const _Float16 *src = xi + static_cast<size_t>(kk) * x_plane + b_src;
+                if constexpr (S2) {
+                    const uint4 lo = *reinterpret_cast<const uint4 *>(src), hi = *reinterpret_cast<const uint4 *>(src + 8);
+                    rb[i] = make_uint4((lo.x & 0xffffu) | (lo.y << 16), (lo.z & 0xffffu) | (lo.w << 16),
+                                       (hi.x & 0xffffu) | (hi.y << 16), (hi.z & 0xffffu) | (hi.w << 16));
+                } else {
+                    rb[i] = *reinterpret_cast<const uint4 *>(src);
+                }
+            }
         }
     };
     auto store_step = [&](const uint4 (&ra)[A_PIECES], const uint4 (&rb)[2]) {
@@ -309,11 +328,12 @@ SPICE_ENV_KNOB(mm_mt_knob, "SPICE_CONV1X1_MT", 0)
 
 }  // namespace spice
 
-extern "C" int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int64_t hw,
-                                        int64_t cout, const float *mean, const float *var, const float *bn_weight,
-                                        const float *bn_bias, float eps, const void *residual, const float *r_mean,
-                                        const float *r_var, const float *r_weight, const float *r_bias, float r_eps,
-                                        int32_t relu, int64_t y_image_stride, void *stream) {
+// x_h, x_w: the plane of x when the convolution has stride 2 (then hw = (x_h / 2) * (x_w / 2)), else 0
+static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int64_t hw,
+                          int64_t cout, const float *mean, const float *var, const float *bn_weight,
+                          const float *bn_bias, float eps, const void *residual, const float *r_mean,
+                          const float *r_var, const float *r_weight, const float *r_bias, float r_eps,
+                          int32_t relu, int64_t y_image_stride, int32_t x_h, int32_t x_w, void *stream) {
     using namespace spice;
     if (n < 0 || cin <= 0 || hw < 0 || cout <= 0) return SPICE_ERR_ARG;
     if (n == 0 || hw == 0) return SPICE_OK;
@@ -333,7 +353,7 @@ extern "C" int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void 
     // option (SPICE_CONV1X1_MT=2), not the default: at 206 registers a compute unit holds two workgroups instead of
     // four, which on MI355X costs more than the traffic saves on every pair of the DeepLabV3+-ResNet-50 forward
     // but one (tools/conv1x1_bench.py: 958 us per forward against 850 us)
-    const bool wide = mm_mt_knob() >= 2 && cout > kMmBM;
+    const bool wide = mm_mt_knob() >= 2 && cout > kMmBM && x_h == 0;
     const int64_t tiles_m = ceil_div(cout, wide ? 2 * kMmBM : kMmBM);
     if (tiles_m * tiles_n > INT32_MAX / n) return SPICE_ERR_UNSUPPORTED;
     MmArgs a;
@@ -355,6 +375,10 @@ extern "C" int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void 
     a.M = static_cast<int>(cout);
     a.K = static_cast<int>(cin);
     a.hw = static_cast<int>(hw);
+    const bool s2 = x_h > 0;
+    a.x_hw = s2 ? x_h * x_w : 0;
+    a.x_w = x_w;
+    a.y_w = s2 ? x_w / 2 : 0;
     a.tiles_m = static_cast<int>(tiles_m);
     a.tiles_n = static_cast<int>(tiles_n);
     a.total_tiles = static_cast<unsigned>(tiles_m * tiles_n * n);
@@ -367,7 +391,13 @@ extern "C" int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void 
                                            : (cin >= 4 * kMmBK && static_cast<int64_t>(a.total_tiles) <= 2 * static_cast<int64_t>(device_cu_count())));
     const bool vec = (cin & 7) == 0 && aligned16(weight);
 #define SPICE_MM_LAUNCH(V, S, T) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, T>), grid, block, 0, st, a)
-    if (wide) {
+#define SPICE_MM_LAUNCH_S2(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, true>), grid, block, 0, st, a)
+    if (s2) {
+        if (deep && vec) SPICE_MM_LAUNCH_S2(true, 3);
+        else if (deep) SPICE_MM_LAUNCH_S2(false, 3);
+        else if (vec) SPICE_MM_LAUNCH_S2(true, 1);
+        else SPICE_MM_LAUNCH_S2(false, 1);
+    } else if (wide) {
         if (vec) SPICE_MM_LAUNCH(true, 1, 2);
         else SPICE_MM_LAUNCH(false, 1, 2);
     } else if (deep) {
@@ -378,6 +408,25 @@ extern "C" int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void 
         else SPICE_MM_LAUNCH(false, 1, 1);
     }
 #undef SPICE_MM_LAUNCH
+#undef SPICE_MM_LAUNCH_S2
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;
+}
+
+extern "C" int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int64_t hw,
+                                        int64_t cout, const float *mean, const float *var, const float *bn_weight,
+                                        const float *bn_bias, float eps, const void *residual, const float *r_mean,
+                                        const float *r_var, const float *r_weight, const float *r_bias, float r_eps,
+                                        int32_t relu, int64_t y_image_stride, void *stream) {
+    return conv1x1_launch(x, weight, y, n, cin, hw, cout, mean, var, bn_weight, bn_bias, eps, residual, r_mean, r_var,
+                          r_weight, r_bias, r_eps, relu, y_image_stride, 0, 0, stream);
+}
+
+extern "C" int spice_conv1x1_stride2_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int32_t h,
+                                         int32_t w, int64_t cout, void *stream) {
+    if (h <= 0 || w <= 0) return SPICE_ERR_ARG;
+    // whole 2x2 cells, and rows of the product that are whole 16-byte pieces
+    if ((h & 1) || (w & 15)) return SPICE_ERR_UNSUPPORTED;
+    return conv1x1_launch(x, weight, y, n, cin, static_cast<int64_t>(h / 2) * (w / 2), cout, nullptr, nullptr, nullptr,
+                          nullptr, 0.0f, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, 0, 0, h, w, stream);
 }

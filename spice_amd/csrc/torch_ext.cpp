@@ -418,7 +418,8 @@ static bool fused_conv1x1_enabled() {
 
 // The plain product.  Where hipBLASLt offers no scratch-free algorithm for a problem size (SPICE_ERR_UNSUPPORTED),
 // the same matrix product goes through at::bmm (rocBLAS): the one operator with a route outside the library.
-Tensor conv1x1_f16(const Tensor &x, const Tensor &weight2d) {
+Tensor conv1x1_f16(const Tensor &x, const Tensor &weight2d, int64_t stride) {
+    TORCH_CHECK_VALUE(stride == 1 || stride == 2, "conv1x1_f16: stride must be 1 or 2");
     TORCH_CHECK_TYPE(x.scalar_type() == at::kHalf && weight2d.scalar_type() == at::kHalf,
                      "conv1x1_f16: x and weight must be fp16");
     TORCH_CHECK(x.is_cuda(), "x is on ", x.device(),
@@ -429,6 +430,15 @@ Tensor conv1x1_f16(const Tensor &x, const Tensor &weight2d) {
                       "conv1x1_f16: x must be contiguous [N,Cin,H,W] and weight contiguous [Cout,Cin]");
     const int64_t n = x.size(0), cin = x.size(1), h = x.size(2), w = x.size(3), cout = weight2d.size(0);
     c10::DeviceGuard guard(x.device());
+    if (stride == 2) {   // the even pixels, picked by the matrix-core kernel while it stages x
+        TORCH_CHECK_VALUE(h % 2 == 0 && w % 16 == 0, "conv1x1_f16: stride 2 needs an even height and a width that is a multiple of 16");
+        Tensor half = at::empty({n, cout, h / 2, w / 2}, x.options());
+        if (half.numel() != 0)
+            check_rc(spice_conv1x1_stride2_f16(x.data_ptr(), weight2d.data_ptr(), half.data_ptr(), n, cin, (int32_t)h, (int32_t)w,
+                                               cout, current_stream(x)),
+                     "spice_conv1x1_stride2_f16");
+        return half;
+    }
     Tensor out = at::empty({n, cout, h, w}, x.options());
     // short sums over many pixels are bound by memory: the hand-written kernel (no tail) moves them faster than the
     // library's product (MI355X, 64 -> 256 channels on 131,072 pixels: 17.8 us against 22.5 us); from K = 512 on
@@ -512,7 +522,7 @@ Tensor conv1x1_bn_act(const Tensor &x, const Tensor &weight2d, const Tensor &mea
             return out;
         }
     }
-    Tensor t = conv1x1_f16(x, weight2d);
+    Tensor t = conv1x1_f16(x, weight2d, 1);
     TORCH_CHECK_VALUE(t.is_contiguous(), "conv1x1_bn_act: the product is not contiguous");
     int rc;
     if (rm != nullptr) {
@@ -563,7 +573,7 @@ TORCH_LIBRARY(spice, m) {
     m.def("bn_act_maxpool(Tensor x, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, bool relu, "
           "bool want_full) -> (Tensor, Tensor)", &bn_act_maxpool);
     m.def("depthwise_conv3x3(Tensor x, Tensor weight, int dilation) -> Tensor", &depthwise_conv3x3);
-    m.def("conv1x1_f16(Tensor x, Tensor weight2d) -> Tensor", &conv1x1_f16);
+    m.def("conv1x1_f16(Tensor x, Tensor weight2d, int stride) -> Tensor", &conv1x1_f16);
     m.def("conv1x1_bn_act(Tensor x, Tensor weight2d, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, "
           "Tensor? residual, Tensor? r_mean, Tensor? r_var, Tensor? r_weight, Tensor? r_bias, float r_eps, bool relu, "
           "int route, Tensor(a!)? out) -> Tensor(a!)", &conv1x1_bn_act);

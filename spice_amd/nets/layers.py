@@ -107,28 +107,43 @@ def _fp16_matrix(weight: torch.Tensor) -> torch.Tensor:
 
 
 class Conv1x1(nn.Conv2d):
-    """nn.Conv2d(in_ch, out_ch, 1, bias=False).  With stride 1 on fp16 activations (autocast) under
-    no_grad on a HIP device the forward is the matrix product it is, W[Cout,Cin] @ X[n][Cin,HW],
-    through the library's hipBLASLt entry point (descriptors and algorithm cached per problem size):
-    fp16 inputs, fp32 accumulation, as MIOpen's 1x1 solvers, without MIOpen's per-call host work
-    (5 us instead of 34 us), which is what bounds a forward of ~70 convolutions once the device work is
-    short.  In every other situation torch's conv2d runs."""
+    """nn.Conv2d(in_ch, out_ch, 1, bias=False).  On fp16 activations (autocast) under no_grad on a HIP
+    device the forward is the matrix product it is, W[Cout,Cin] @ X[n][Cin,HW] (fp16 inputs, fp32
+    accumulation, as MIOpen's 1x1 solvers): through the library's matrix-core kernel or its hipBLASLt
+    entry point with stride 1, and through the matrix-core kernel, which picks the even pixels itself,
+    with stride 2 (MIOpen serves that case with a strided copy, two layout transposes and a product).
+    In every other situation torch's conv2d runs."""
 
     def __init__(self, in_channels: int, out_channels: int, stride: int = 1):
         super().__init__(in_channels, out_channels, 1, stride=stride, bias=False)
 
-    def takes_matrix_path(self, x_dtype: torch.dtype) -> bool:
-        return (_LIBRARY_FORWARD and self.stride == (1, 1) and self.bias is None and self.groups == 1
-                and self.padding == (0, 0)
+    def _plain_fp16(self, x_dtype: torch.dtype) -> bool:
+        return (_LIBRARY_FORWARD and self.bias is None and self.groups == 1 and self.padding == (0, 0)
                 and (x_dtype == torch.float16 or
                      (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16)))
 
+    def takes_matrix_path(self, x_dtype: torch.dtype) -> bool:
+        return self.stride == (1, 1) and self._plain_fp16(x_dtype)
+
+    def served_by_library(self, x_dtype: torch.dtype, height: int, width: int) -> bool:
+        """Whether forward() on a plane of this size is a launch of the library (no MIOpen call, no solver lookup)."""
+        if self.takes_matrix_path(x_dtype):
+            return True
+        return self.stride == (2, 2) and self._plain_fp16(x_dtype) and height % 2 == 0 and width % 16 == 0
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and self.takes_matrix_path(x.dtype):
-            if x.dtype != torch.float16:
-                x = x.to(torch.float16)   # what autocast does to a convolution's input
-            if x.is_contiguous():
-                return ops.conv1x1_f16(x, _fp16_matrix(self.weight))
+        if not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4:
+            if self.takes_matrix_path(x.dtype):
+                if x.dtype != torch.float16:
+                    x = x.to(torch.float16)   # what autocast does to a convolution's input
+                if x.is_contiguous():
+                    return ops.conv1x1_f16(x, _fp16_matrix(self.weight))
+            elif self.served_by_library(x.dtype, x.shape[2], x.shape[3]):
+                # the projection shortcut of a stage that halves the resolution: the product over the even pixels
+                if x.dtype != torch.float16:
+                    x = x.to(torch.float16)
+                if x.is_contiguous():
+                    return ops.conv1x1_f16(x, _fp16_matrix(self.weight), stride=2)
         return super().forward(x)
 
 

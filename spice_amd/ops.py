@@ -475,14 +475,15 @@ def depthwise_conv3x3(x: torch.Tensor, weight: torch.Tensor, dilation: int = 1) 
 _conv1x1_fn = None
 
 
-def conv1x1_f16(x: torch.Tensor, weight2d: torch.Tensor) -> torch.Tensor:
-    """weight2d[Cout, Cin] @ x[n][Cin, H*W] for fp16 NCHW x: a 1x1 stride-1 convolution without bias.
-    hipBLASLt with descriptors and algorithm cached per problem size; where hipBLASLt offers no
-    scratch-free algorithm for a size the product goes through torch.bmm (rocBLAS)."""
+def conv1x1_f16(x: torch.Tensor, weight2d: torch.Tensor, stride: int = 1) -> torch.Tensor:
+    """weight2d[Cout, Cin] @ x[n][Cin, H*W] for fp16 NCHW x: a 1x1 convolution without bias.  Stride 1: the
+    matrix-core kernel for K <= 256 and planes of a multiple of 8 pixels, else hipBLASLt with descriptors and
+    algorithm cached per problem size (torch.bmm where hipBLASLt offers no scratch-free algorithm).  Stride 2
+    (even height, width a multiple of 16): the matrix-core kernel, which picks the even pixels while it stages x."""
     global _conv1x1_fn
     if _conv1x1_fn is None:
         _conv1x1_fn = spice_ops().conv1x1_f16
-    return _conv1x1_fn(x, weight2d)
+    return _conv1x1_fn(x, weight2d, stride)
 
 
 _conv1x1_bn_fn = None

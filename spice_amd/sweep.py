@@ -215,7 +215,7 @@ class SensitivitySweep:
             key = (n, cin, h, w, cout, groups, mod.kernel_size, mod.stride, mod.padding, mod.dilation)
             if key in self._warmed or groups == cin:  # depthwise convolutions do not go through MIOpen
                 continue
-            if isinstance(mod, Conv1x1) and mod.takes_matrix_path(self.autocast_dtype or in_dtype):
+            if isinstance(mod, Conv1x1) and mod.served_by_library(self.autocast_dtype or in_dtype, h, w):
                 continue  # a plain matrix product: no solver lookup to get out of the way
             self._warmed.add(key)
             dt = self.autocast_dtype or in_dtype

@@ -152,3 +152,44 @@ def test_fused_writes_into_a_channel_slice(dev, route):
         ops.conv1x1_bn_act(x, wt, bn, res, None, True, out=both[:, :cout, :, ::2])
     with torch.no_grad(), pytest.raises(TypeError):
         ops.conv1x1_bn_act(x, wt, bn, res, None, True, out=both.float()[:, :cout])
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16, 32, 96), (1, 40, 8, 16, 130), (3, 230, 4, 16, 77), (8, 256, 128, 128, 512),
+                                   (1, 512, 16, 32, 64), (2, 8, 2, 16, 5)])
+def test_stride2_product(dev, shape):
+    """The 1x1 convolution of stride 2 (projection shortcuts): exact on integer data against the product over the
+    even pixels, and within an fp16 step of torch's strided convolution on random data."""
+    n, cin, h, w, cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + 2)
+    x = torch.randint(-3, 4, (n, cin, h, w), generator=g).half()
+    wt = torch.randint(-2, 3, (cout, cin), generator=g).half()
+    exact = torch.einsum("oc,nchw->nohw", wt.double(), x[:, :, ::2, ::2].double()).half().contiguous()
+    got = ops.conv1x1_f16(x.to(dev), wt.to(dev), stride=2)
+    assert got.shape == (n, cout, h // 2, w // 2) and got.dtype == torch.float16 and torch.equal(got.cpu(), exact)
+    x = torch.randn(n, cin, h, w, generator=g).half().to(dev)
+    wt = (torch.randn(cout, cin, generator=g) / cin ** 0.5).half().to(dev)
+    got = ops.conv1x1_f16(x, wt, stride=2)
+    there = torch.nn.functional.conv2d(x, wt.view(cout, cin, 1, 1), stride=2)
+    scale = float(there.float().abs().max())
+    assert float((got.float() - there.float()).abs().max()) <= 2.0 ** -9 * scale + 1e-6
+
+
+def test_stride2_module_and_limits(dev):
+    from spice_amd.nets.layers import Conv1x1
+    conv = Conv1x1(16, 24, stride=2).to(dev)
+    x = torch.randn(2, 16, 8, 32, device=dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        assert conv.served_by_library(x.dtype, 8, 32) and not conv.served_by_library(x.dtype, 8, 24)
+        got = conv(x)
+        handle = conv.register_forward_hook(lambda m, i, o: None)   # does not change the route of a plain module call
+        again = conv(x)
+        handle.remove()
+        there = torch.nn.functional.conv2d(x.half(), conv.weight.half(), stride=2)
+        odd = conv(torch.randn(2, 16, 8, 24, device=dev))   # width not a multiple of 16: torch's convolution
+    assert got.dtype == torch.float16 and torch.equal(got, again)
+    assert float((got.float() - there.float()).abs().max()) <= 2.0 ** -9 * float(there.float().abs().max()) + 1e-6
+    assert odd.shape == (2, 24, 4, 12)
+    with pytest.raises(ValueError):
+        ops.conv1x1_f16(x.half(), conv.weight.half().view(24, 16), stride=3)
+    with pytest.raises(ValueError):
+        ops.conv1x1_f16(x.half()[..., :24].contiguous(), conv.weight.half().view(24, 16), stride=2)

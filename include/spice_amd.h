@@ -379,6 +379,10 @@ int spice_conv1x1_f16(const void *x, const void *weight, void *y, int64_t n, int
  * the tail is spice_bn_act's / spice_bn_act_dual's arithmetic, so the values are those of the two calls up to
  * the order of the fp32 sums.  mean == NULL: the plain product (no tail; residual must be NULL).
  * residual is [n, Cout, HW] fp16 or NULL; the r_* vectors are all NULL or all set (then residual is required).
+ * p_mean .. p_bias (all NULL or all set, fp32 [Cin]): x is the RAW result of the convolution before and its own
+ * batch-norm (+ ReLU if p_relu) is still pending: the kernel applies it to x on the way in, rounded to fp16 as
+ * spice_bn_act would have stored it, so that launch and its round trip through memory are gone (conv2 -> bn2 -> relu ->
+ * conv3 -> bn3 of a bottleneck: one launch behind the 3x3 convolution).  Cin <= 512, else SPICE_ERR_UNSUPPORTED.
  * y_image_stride: elements between the images of y (0 = Cout * HW, dense); larger when y is a channel slice of a
  * concatenation buffer.  HW and y_image_stride must be multiples of 8 and x, y, residual 16-byte aligned, else
  * SPICE_ERR_UNSUPPORTED (callers then use the two calls above).  Holds no state and uses no scratch memory. */
@@ -386,7 +390,8 @@ int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void *y, int64_t
                              int64_t cout, const float *mean, const float *var, const float *bn_weight,
                              const float *bn_bias, float eps, const void *residual, const float *r_mean,
                              const float *r_var, const float *r_weight, const float *r_bias, float r_eps,
-                             int32_t relu, int64_t y_image_stride, void *stream);
+                             int32_t relu, int64_t y_image_stride, const float *p_mean, const float *p_var,
+                             const float *p_weight, const float *p_bias, float p_eps, int32_t p_relu, void *stream);
 
 /* The plain product for a 1x1 convolution of stride 2 (the projection shortcuts of the ResNet stages that halve the
  * resolution): y[n][Cout, (h/2)*(w/2)] = weight[Cout, Cin] @ x[n][Cin, even rows, even columns], by the same

@@ -105,7 +105,8 @@ SIGNATURES = {
     "spice_conv1x1_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "spice_conv1x1_bn_act_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
-                                           c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_int64, c_void_p]),
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_int64,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_void_p]),
     "spice_upsample_bilinear": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_int32,
                                           c_int32, c_int32, c_int32, c_float, c_float, c_void_p]),
     "spice_upsample_bilinear_into": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_int32,

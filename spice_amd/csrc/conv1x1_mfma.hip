@@ -31,6 +31,7 @@ constexpr int kMmBM = 128, kMmBN = 64, kMmBK = 64;
 constexpr int kMmAPitch = 72;    // halfs
 constexpr int kMmBPitch = 64;    // halfs (swizzled, no padding)
 constexpr int kMmCPitch = 72;    // halfs
+constexpr int kMmPreMaxK = 512;  // input channels whose pending batch-norm the kernel can hold in LDS (8 KB)
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
@@ -47,7 +48,9 @@ struct MmArgs {
     const _Float16 *res;    // [n][M][hw] or null
     const float *mean, *var, *weight, *bias;           // null mean: no batch-norm, no tail
     const float *r_mean, *r_var, *r_weight, *r_bias;   // batch-norm of the residual, or null
-    float eps, r_eps;
+    const float *p_mean, *p_var, *p_weight, *p_bias;   // batch-norm (+ ReLU) still to be applied to x, per INPUT channel, or null
+    float eps, r_eps, p_eps;
+    int p_relu;
     int M, K, hw;           // hw: pixels per image of the PRODUCT
     int x_hw, x_w, y_w;     // stride 2 only: pixels per image and row width of x, row width of the product
     int tiles_m, tiles_n;   // per image
@@ -104,13 +107,17 @@ __device__ __forceinline__ half2_t bn_tail_pair(half2_t x, half2_t r, const BnCh
 
 // S2: the convolution has stride 2 - the product's pixel (y, x) is x's pixel (2y, 2x): a piece of 8 product pixels
 // is the even elements of 16 consecutive pixels of x (two 16-byte loads).
-template <bool A_VEC, int STAGES, int MT, bool S2 = false>
+// PRE: x is the raw result of the convolution before; its batch-norm and ReLU (per input channel = per row of the X
+// tile) are applied to the pieces on their way from the staging registers into LDS, rounded to fp16 as the separate
+// batch-norm launch stores them: that launch, its read of x and its write of the activated tensor are gone.
+template <bool A_VEC, int STAGES, int MT, bool S2 = false, bool PRE = false>
 __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void conv1x1_bn_act_mfma_kernel(MmArgs a) {
     constexpr int BM = kMmBM * MT;          // channels per workgroup: MT 32-channel product tiles per wave
     constexpr int A_PIECES = 4 * MT;        // 16-byte pieces of A per lane and K step
     constexpr int ROWS = 4 * MT;            // rows per lane in the row-major pass of the epilogue
     __shared__ __attribute__((aligned(16))) _Float16 lds[BM * kMmAPitch + kMmBK * kMmBPitch];
     static_assert(kMmCPitch <= kMmAPitch, "the C image fits in the A image's storage");
+    __shared__ __attribute__((aligned(16))) float pre[PRE ? kMmPreMaxK * 4 : 4];   // (mean, inv, weight, bias) per input channel
     _Float16 *As = lds;
     _Float16 *Bs = lds + BM * kMmAPitch;
 
@@ -123,6 +130,12 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    if constexpr (PRE) {   // read in store_step, behind the barrier at the top of the K loop
+        for (int k = tid; k < a.K; k += kMmThreads) {
+            const BnChannel c = bn_channel_of(a.p_mean, a.p_var, a.p_weight, a.p_bias, a.p_eps, k);
+            *reinterpret_cast<float4 *>(pre + 4 * k) = make_float4(c.mean, c.inv, c.weight, c.bias);
+        }
+    }
 
     // the row-major pass of the epilogue: lane takes 8 consecutive pixels of one channel, ROWS such pieces
     const int e_pc = (tid & 7) * 8, e_row = tid >> 3;   // rows e_row + 32 i
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
             }
         }
     };
-    auto store_step = [&](const uint4 (&ra)[A_PIECES], const uint4 (&rb)[2]) {
+    auto store_step = [&](int k0, const uint4 (&ra)[A_PIECES], const uint4 (&rb)[2]) {
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
             const int c = tid + kMmThreads * i;
@@ -187,7 +200,23 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = tid + kMmThreads * i;
-            *reinterpret_cast<uint4 *>(Bs + mm_b_offset(c >> 3, c & 7)) = rb[i];
+            uint4 piece = rb[i];
+            if constexpr (PRE) {
+                const int kk = k0 + (c >> 3);
+                if (kk < a.K) {   // rows beyond K stay zero
+                    const float4 q = *reinterpret_cast<const float4 *>(pre + 4 * kk);
+                    const BnChannel ch = {q.x, q.y, q.z, q.w};
+                    half8_t v = __builtin_bit_cast(half8_t, piece);
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const half2_t o = bn_tail_pair<false, false>(half2_t{v[e], v[e + 1]}, half2_t{0, 0}, ch, ch, a.p_relu);
+                        v[e] = o[0];
+                        v[e + 1] = o[1];
+                    }
+                    piece = __builtin_bit_cast(uint4, v);
+                }
+            }
+            *reinterpret_cast<uint4 *>(Bs + mm_b_offset(c >> 3, c & 7)) = piece;
         }
     };
 
@@ -256,7 +285,7 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
             const int k = k0 + st * kMmBK;
             if (k < a.K) {   // uniform
                 __syncthreads();   // every wave has read the previous step's images
-                store_step(ra_all[st], rb_all[st]);
+                store_step(k, ra_all[st], rb_all[st]);
                 __syncthreads();
                 if (k + STAGES * kMmBK < a.K) load_step(k + STAGES * kMmBK, ra_all[st], rb_all[st]);   // in flight from here
                 multiply_step();
@@ -333,7 +362,9 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
                           int64_t cout, const float *mean, const float *var, const float *bn_weight,
                           const float *bn_bias, float eps, const void *residual, const float *r_mean,
                           const float *r_var, const float *r_weight, const float *r_bias, float r_eps,
-                          int32_t relu, int64_t y_image_stride, int32_t x_h, int32_t x_w, void *stream) {
+                          int32_t relu, int64_t y_image_stride, int32_t x_h, int32_t x_w, const float *p_mean,
+                          const float *p_var, const float *p_weight, const float *p_bias, float p_eps, int32_t p_relu,
+                          void *stream) {
     using namespace spice;
     if (n < 0 || cin <= 0 || hw < 0 || cout <= 0) return SPICE_ERR_ARG;
     if (n == 0 || hw == 0) return SPICE_OK;
@@ -342,6 +373,8 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     if (mean == nullptr && (residual != nullptr || r_mean != nullptr)) return SPICE_ERR_ARG;
     if (r_mean != nullptr && (residual == nullptr || r_var == nullptr || r_weight == nullptr || r_bias == nullptr))
         return SPICE_ERR_ARG;
+    if (p_mean != nullptr && (p_var == nullptr || p_weight == nullptr || p_bias == nullptr)) return SPICE_ERR_ARG;
+    if (p_mean != nullptr && (cin > kMmPreMaxK || x_h > 0)) return SPICE_ERR_UNSUPPORTED;
     // 16-byte pieces of whole rows of X, R and Y: the plane size must be a multiple of 8 halfs
     if (y_image_stride == 0) y_image_stride = cout * hw;   // dense
     if (y_image_stride < cout * hw) return SPICE_ERR_ARG;
@@ -353,7 +386,7 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     // option (SPICE_CONV1X1_MT=2), not the default: at 206 registers a compute unit holds two workgroups instead of
     // four, which on MI355X costs more than the traffic saves on every pair of the DeepLabV3+-ResNet-50 forward
     // but one (tools/conv1x1_bench.py: 958 us per forward against 850 us)
-    const bool wide = mm_mt_knob() >= 2 && cout > kMmBM && x_h == 0;
+    const bool wide = mm_mt_knob() >= 2 && cout > kMmBM && x_h == 0 && p_mean == nullptr;
     const int64_t tiles_m = ceil_div(cout, wide ? 2 * kMmBM : kMmBM);
     if (tiles_m * tiles_n > INT32_MAX / n) return SPICE_ERR_UNSUPPORTED;
     MmArgs a;
@@ -370,8 +403,14 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     a.r_var = r_var;
     a.r_weight = r_weight;
     a.r_bias = r_bias;
+    a.p_mean = p_mean;
+    a.p_var = p_var;
+    a.p_weight = p_weight;
+    a.p_bias = p_bias;
     a.eps = eps;
     a.r_eps = r_eps;
+    a.p_eps = p_eps;
+    a.p_relu = p_relu ? 1 : 0;
     a.M = static_cast<int>(cout);
     a.K = static_cast<int>(cin);
     a.hw = static_cast<int>(hw);
@@ -392,7 +431,13 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     const bool vec = (cin & 7) == 0 && aligned16(weight);
 #define SPICE_MM_LAUNCH(V, S, T) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, T>), grid, block, 0, st, a)
 #define SPICE_MM_LAUNCH_S2(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, true>), grid, block, 0, st, a)
-    if (s2) {
+#define SPICE_MM_LAUNCH_PRE(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, false, true>), grid, block, 0, st, a)
+    if (p_mean != nullptr) {
+        if (deep && vec) SPICE_MM_LAUNCH_PRE(true, 3);
+        else if (deep) SPICE_MM_LAUNCH_PRE(false, 3);
+        else if (vec) SPICE_MM_LAUNCH_PRE(true, 1);
+        else SPICE_MM_LAUNCH_PRE(false, 1);
+    } else if (s2) {
         if (deep && vec) SPICE_MM_LAUNCH_S2(true, 3);
         else if (deep) SPICE_MM_LAUNCH_S2(false, 3);
         else if (vec) SPICE_MM_LAUNCH_S2(true, 1);
@@ -409,6 +454,7 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     }
 #undef SPICE_MM_LAUNCH
 #undef SPICE_MM_LAUNCH_S2
+#undef SPICE_MM_LAUNCH_PRE
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;
 }
@@ -417,9 +463,12 @@ extern "C" int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void 
                                         int64_t cout, const float *mean, const float *var, const float *bn_weight,
                                         const float *bn_bias, float eps, const void *residual, const float *r_mean,
                                         const float *r_var, const float *r_weight, const float *r_bias, float r_eps,
-                                        int32_t relu, int64_t y_image_stride, void *stream) {
+                                        int32_t relu, int64_t y_image_stride, const float *p_mean, const float *p_var,
+                                        const float *p_weight, const float *p_bias, float p_eps, int32_t p_relu,
+                                        void *stream) {
     return conv1x1_launch(x, weight, y, n, cin, hw, cout, mean, var, bn_weight, bn_bias, eps, residual, r_mean, r_var,
-                          r_weight, r_bias, r_eps, relu, y_image_stride, 0, 0, stream);
+                          r_weight, r_bias, r_eps, relu, y_image_stride, 0, 0, p_mean, p_var, p_weight, p_bias, p_eps, p_relu,
+                          stream);
 }
 
 extern "C" int spice_conv1x1_stride2_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int32_t h,
@@ -428,5 +477,6 @@ extern "C" int spice_conv1x1_stride2_f16(const void *x, const void *weight, void
     // whole 2x2 cells, and rows of the product that are whole 16-byte pieces
     if ((h & 1) || (w & 15)) return SPICE_ERR_UNSUPPORTED;
     return conv1x1_launch(x, weight, y, n, cin, static_cast<int64_t>(h / 2) * (w / 2), cout, nullptr, nullptr, nullptr,
-                          nullptr, 0.0f, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, 0, 0, h, w, stream);
+                          nullptr, 0.0f, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, 0, 0, h, w, nullptr, nullptr, nullptr,
+                          nullptr, 0.0f, 0, stream);
 }

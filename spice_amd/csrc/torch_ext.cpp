@@ -446,7 +446,8 @@ Tensor conv1x1_f16(const Tensor &x, const Tensor &weight2d, int64_t stride) {
     if (cin <= 256 && fused_conv1x1_enabled()) {
         const int frc = spice_conv1x1_bn_act_f16(x.data_ptr(), weight2d.data_ptr(), out.data_ptr(), n, cin, h * w, cout,
                                                  nullptr, nullptr, nullptr, nullptr, 0.0f, nullptr, nullptr, nullptr, nullptr,
-                                                 nullptr, 0.0f, 0, 0, current_stream(x));
+                                                 nullptr, 0.0f, 0, 0, nullptr, nullptr, nullptr, nullptr, 0.0f, 0,
+                                                 current_stream(x));
         if (frc != SPICE_ERR_UNSUPPORTED) {
             check_rc(frc, "spice_conv1x1_bn_act_f16 (plain product)");
             return out;
@@ -469,7 +470,9 @@ Tensor conv1x1_bn_act(const Tensor &x, const Tensor &weight2d, const Tensor &mea
                       const Tensor &weight, const Tensor &bias, double eps, const c10::optional<Tensor> &residual,
                       const c10::optional<Tensor> &r_mean, const c10::optional<Tensor> &r_var,
                       const c10::optional<Tensor> &r_weight, const c10::optional<Tensor> &r_bias, double r_eps, bool relu,
-                      int64_t route, const c10::optional<Tensor> &out_opt) {
+                      int64_t route, const c10::optional<Tensor> &out_opt, const c10::optional<Tensor> &p_mean,
+                      const c10::optional<Tensor> &p_var, const c10::optional<Tensor> &p_weight,
+                      const c10::optional<Tensor> &p_bias, double p_eps, bool p_relu) {
     TORCH_CHECK_VALUE(route >= 0 && route <= 2, "conv1x1_bn_act: route must be 0 (choose), 1 (one launch) or 2 (two launches)");
     TORCH_CHECK_TYPE(x.scalar_type() == at::kHalf && weight2d.scalar_type() == at::kHalf,
                      "conv1x1_bn_act: x and weight must be fp16");
@@ -506,6 +509,20 @@ Tensor conv1x1_bn_act(const Tensor &x, const Tensor &weight2d, const Tensor &mea
         rw = r_weight->data_ptr<float>();
         rb = r_bias->data_ptr<float>();
     }
+    // a batch-norm (+ ReLU) of x that is still pending: per input channel
+    const float *pm = nullptr, *pv = nullptr, *pw = nullptr, *pb = nullptr;
+    if (p_mean.has_value()) {
+        TORCH_CHECK_VALUE(p_var.has_value() && p_weight.has_value() && p_bias.has_value(),
+                          "conv1x1_bn_act: a pending batch-norm of x needs all four of its vectors");
+        for (const Tensor *p : {&*p_mean, &*p_var, &*p_weight, &*p_bias})
+            TORCH_CHECK_TYPE(p->scalar_type() == at::kFloat && p->device() == x.device() && p->numel() == cin &&
+                                 p->is_contiguous(),
+                             "conv1x1_bn_act: the pending batch-norm's vectors must be contiguous fp32 [", cin, "]");
+        pm = p_mean->data_ptr<float>();
+        pv = p_var->data_ptr<float>();
+        pw = p_weight->data_ptr<float>();
+        pb = p_bias->data_ptr<float>();
+    }
     c10::DeviceGuard guard(x.device());
     if (out_opt.has_value()) check_slice_out(*out_opt, x, n, c, h, w, at::kHalf, "conv1x1_bn_act");
     if (route == 1 || (route == 0 && fused_conv1x1_enabled())) {
@@ -515,14 +532,22 @@ Tensor conv1x1_bn_act(const Tensor &x, const Tensor &weight2d, const Tensor &mea
                               : spice_conv1x1_bn_act_f16(x.data_ptr(), weight2d.data_ptr(), out.data_ptr(), n, cin, h * w, c,
                                                          mean.data_ptr<float>(), var.data_ptr<float>(),
                                                          weight.data_ptr<float>(), bias.data_ptr<float>(), (float)eps, res, rm,
-                                                         rv, rw, rb, (float)r_eps, relu ? 1 : 0, image_stride,
-                                                         current_stream(x));
+                                                         rv, rw, rb, (float)r_eps, relu ? 1 : 0, image_stride, pm, pv, pw, pb,
+                                                         (float)p_eps, p_relu ? 1 : 0, current_stream(x));
         if (rc != SPICE_ERR_UNSUPPORTED || route == 1) {
             check_rc(rc, "spice_conv1x1_bn_act_f16");
             return out;
         }
     }
-    Tensor t = conv1x1_f16(x, weight2d, 1);
+    Tensor xin = x;
+    if (pm != nullptr) {   // the pending batch-norm as a launch of its own
+        xin = at::empty_like(x);
+        if (x.numel() != 0)
+            check_rc(spice_bn_act(x.data_ptr(), nullptr, xin.data_ptr(), 1, pm, pv, pw, pb, (float)p_eps, n, cin, h * w,
+                                  p_relu ? 1 : 0, current_stream(x)),
+                     "spice_bn_act (pending batch-norm of x)");
+    }
+    Tensor t = conv1x1_f16(xin, weight2d, 1);
     TORCH_CHECK_VALUE(t.is_contiguous(), "conv1x1_bn_act: the product is not contiguous");
     int rc;
     if (rm != nullptr) {
@@ -576,5 +601,6 @@ TORCH_LIBRARY(spice, m) {
     m.def("conv1x1_f16(Tensor x, Tensor weight2d, int stride) -> Tensor", &conv1x1_f16);
     m.def("conv1x1_bn_act(Tensor x, Tensor weight2d, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, "
           "Tensor? residual, Tensor? r_mean, Tensor? r_var, Tensor? r_weight, Tensor? r_bias, float r_eps, bool relu, "
-          "int route, Tensor(a!)? out) -> Tensor(a!)", &conv1x1_bn_act);
+          "int route, Tensor(a!)? out, Tensor? p_mean, Tensor? p_var, Tensor? p_weight, Tensor? p_bias, float p_eps, "
+          "bool p_relu) -> Tensor(a!)", &conv1x1_bn_act);
 }

@@ -165,13 +165,16 @@ def _into(out, y):
 
 
 def conv1x1_bn(conv: Conv1x1, bn: BatchNormAct2d, x, residual=None, residual_norm: Optional[nn.BatchNorm2d] = None,
-               out: Optional[torch.Tensor] = None):
+               out: Optional[torch.Tensor] = None, pre_norm: Optional[BatchNormAct2d] = None):
     """bn(conv(x) [, residual [, residual_norm]]).  On the inference path of a HIP device, where `conv` is the
     library's matrix product and `bn` the library's fused tail, the pair is ONE call of the extension (one launch of
     the matrix-core kernel that normalises the product before storing it; two launches where that kernel does not
     take the shapes) instead of two module calls.  Modules carrying forward hooks, symbolic tracing, training and
     every other situation take the modules one after the other.  `out`: where to write the result (a channel slice
-    of a concatenation buffer); the one-launch route writes there directly, every other route copies."""
+    of a concatenation buffer); the one-launch route writes there directly, every other route copies.
+    `pre_norm`: x is the raw result of the convolution before and this batch-norm (+ its ReLU) is still to be applied
+    to it: bn(conv(pre_norm(x)) ...).  The one-launch route applies it to x on the way in (no launch, no round trip
+    of the activated tensor through memory); every other route calls the module first."""
     if (isinstance(x, torch.Tensor) and _LIBRARY_FORWARD and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4
             and not torch.nn.modules.module._global_forward_hooks
             and not (_hooked(conv) or _hooked(bn)) and conv.takes_matrix_path(x.dtype) and _plain_inference_norm(bn)
@@ -184,11 +187,22 @@ def conv1x1_bn(conv: Conv1x1, bn: BatchNormAct2d, x, residual=None, residual_nor
                 and residual_norm.num_features == bn.num_features
         if out is not None:
             ok = ok and out.dtype == torch.float16
+        pre = None
+        if pre_norm is not None and x.dtype == torch.float16 and _plain_inference_norm(pre_norm) and not _hooked(pre_norm) \
+                and pre_norm.num_features == conv.in_channels:
+            pre = pre_norm   # the extension falls back to a launch of its own where the kernel cannot take it along
+        elif pre_norm is not None:
+            x = pre_norm(x)
         if ok:
             if x.dtype != torch.float16:
                 x = x.to(torch.float16)   # what autocast does to a convolution's input
             if x.is_contiguous():
-                return ops.conv1x1_bn_act(x, _fp16_matrix(conv.weight), bn, residual, residual_norm, bn.relu_after, out=out)
+                return ops.conv1x1_bn_act(x, _fp16_matrix(conv.weight), bn, residual, residual_norm, bn.relu_after, out=out,
+                                          pre_bn=pre, pre_relu=pre.relu_after if pre is not None else False)
+        if pre is not None:
+            x = pre_norm(x)
+    elif pre_norm is not None:
+        x = pre_norm(x)
     if residual is None:
         return _into(out, bn(conv(x)))
     if residual_norm is None:

@@ -31,14 +31,16 @@ class Bottleneck(nn.Module):
                 nn.BatchNorm2d(planes * 4))
 
     def forward(self, x):
-        out = self.bn2(self.conv2(conv1x1_bn(self.conv1, self.bn1, x)))
+        # bn2 (+ ReLU) rides along with conv3 at inference: the kernel applies it to the 3x3 convolution's raw result on
+        # the way in
+        raw = self.conv2(conv1x1_bn(self.conv1, self.bn1, x))
         if self.downsample is None:
-            return conv1x1_bn(self.conv3, self.bn3, out, x)
+            return conv1x1_bn(self.conv3, self.bn3, raw, x, pre_norm=self.bn2)
         if not isinstance(x, torch.Tensor):
             # symbolic tracing (the channel-coupling analysis): the shortcut as the plain composition it is
-            return self.bn3(self.conv3(out), self.downsample(x))
+            return self.bn3(self.conv3(self.bn2(raw)), self.downsample(x))
         # the shortcut's batch-norm rides along with bn3: relu(bn3(.) + bn_ds(conv_ds(x))) in one launch at inference
-        return conv1x1_bn(self.conv3, self.bn3, out, self.downsample[0](x), self.downsample[1])
+        return conv1x1_bn(self.conv3, self.bn3, raw, self.downsample[0](x), self.downsample[1], pre_norm=self.bn2)
 
 
 class ResNet50Encoder(nn.Module):

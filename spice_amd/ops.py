@@ -491,17 +491,21 @@ _conv1x1_bn_fn = None
 
 def conv1x1_bn_act(x: torch.Tensor, weight2d: torch.Tensor, bn: "torch.nn.BatchNorm2d",
                    residual: Optional[torch.Tensor] = None, res_bn: Optional["torch.nn.BatchNorm2d"] = None,
-                   relu: bool = False, route: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """relu?(bn(weight2d @ x) [+ residual | + res_bn(residual)]) from one call of the extension.  route 0: the
-    matrix-core kernel that applies the tail to the product before storing it (ONE launch) where it takes the shapes
-    (plane size a multiple of 8), else conv1x1_f16 followed by the batch-norm tail in place (two launches);
-    route 1 / 2: that kernel / the two launches, explicitly.  `out`: write into this tensor, which may be a channel
-    slice of a larger NCHW tensor (a concatenation buffer), instead of a new one."""
+                   relu: bool = False, route: int = 0, out: Optional[torch.Tensor] = None,
+                   pre_bn: Optional["torch.nn.BatchNorm2d"] = None, pre_relu: bool = False) -> torch.Tensor:
+    """relu?(bn(weight2d @ x') [+ residual | + res_bn(residual)]) from one call of the extension, with
+    x' = x, or relu?(pre_bn(x)) when x is the raw result of the convolution before and its own batch-norm is still
+    pending.  route 0: the matrix-core kernel that applies the tail to the product before storing it (and pre_bn to x
+    on the way in): ONE launch, where it takes the shapes (plane size a multiple of 8; at most 512 input channels
+    with pre_bn); else the separate launches (pre_bn, conv1x1_f16, the batch-norm tail in place); route 1 / 2: that
+    kernel / the separate launches, explicitly.  `out`: write into this tensor, which may be a channel slice of a
+    larger NCHW tensor (a concatenation buffer), instead of a new one."""
     global _conv1x1_bn_fn
     if _conv1x1_bn_fn is None:
         _conv1x1_bn_fn = spice_ops().conv1x1_bn_act
-    if res_bn is None:
-        return _conv1x1_bn_fn(x, weight2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, residual,
-                              None, None, None, None, 0.0, relu, route, out)
-    return _conv1x1_bn_fn(x, weight2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, residual,
-                          res_bn.running_mean, res_bn.running_var, res_bn.weight, res_bn.bias, res_bn.eps, relu, route, out)
+    r = (None, None, None, None, 0.0) if res_bn is None else (res_bn.running_mean, res_bn.running_var, res_bn.weight,
+                                                               res_bn.bias, res_bn.eps)
+    p = (None, None, None, None, 0.0) if pre_bn is None else (pre_bn.running_mean, pre_bn.running_var, pre_bn.weight,
+                                                              pre_bn.bias, pre_bn.eps)
+    return _conv1x1_bn_fn(x, weight2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, residual, *r, relu,
+                          route, out, *p, pre_relu)

@@ -73,7 +73,7 @@ def main():
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             call = lambda i: nat.lib().spice_conv1x1_bn_act_f16(xs[i % n_buf].data_ptr(), w.data_ptr(), y.data_ptr(), args.batch, cin,
                                                                  side * side, cout, null, null, null, null, 0.0, null, null, null,
-                                                                 null, null, 0.0, 0, 0, stream)
+                                                                 null, null, 0.0, 0, 0, null, null, null, null, 0.0, 0, stream)
             for i in range(3):
                 call(i)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -400,6 +400,20 @@ int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void *y, int64_t
 int spice_conv1x1_stride2_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int32_t h,
                               int32_t w, int64_t cout, void *stream);
 
+/* A 3x3 convolution (padding = dilation, no bias) of fp16 NCHW activations with the inference batch-norm (+ ReLU)
+ * behind it, in one launch of the same matrix-core kernel: the nine taps are nine shifted 1x1 products in one sum
+ * (conv2 + bn2 + relu of the bottlenecks of pruning/models.py:35-39's ResNet encoders, which torch serves with
+ * MIOpen's Winograd / implicit-GEMM kernels and a separate batch-norm launch).
+ *   y[n][Cout, (h/stride)*(w/stride)] = relu?( bn( sum over taps of weight9[:, tap, :] @ x[n] shifted by the tap ) )
+ * weight9 is the convolution's weight as [Cout][9][Cin] (tap-major: weight.permute(0, 2, 3, 1)), fp16.
+ * stride 1 or 2, dilation 1..7; h and w multiples of the stride, w / stride a multiple of 8, w >= 8; else
+ * SPICE_ERR_UNSUPPORTED (callers keep torch's convolution).  fp32 sums in (tap, channel) order; mean == NULL: no
+ * batch-norm.  Holds no state and uses no scratch memory. */
+int spice_conv3x3_bn_act_f16(const void *x, const void *weight9, void *y, int64_t n, int64_t cin, int32_t h,
+                             int32_t w, int64_t cout, int32_t stride, int32_t dilation, const float *mean,
+                             const float *var, const float *bn_weight, const float *bn_bias, float eps,
+                             int32_t relu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

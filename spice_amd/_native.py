@@ -101,6 +101,8 @@ SIGNATURES = {
                                                   c_int32, c_int32, c_void_p]),
     "spice_bn_act_maxpool_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                            c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    "spice_conv3x3_bn_act_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int64, c_int32,
+                                           c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_void_p]),
     "spice_conv1x1_stride2_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int64, c_void_p]),
     "spice_conv1x1_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "spice_conv1x1_bn_act_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,

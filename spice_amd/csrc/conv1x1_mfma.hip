@@ -52,7 +52,8 @@ struct MmArgs {
     float eps, r_eps, p_eps;
     int p_relu;
     int M, K, hw;           // hw: pixels per image of the PRODUCT
-    int x_hw, x_w, y_w;     // stride 2 only: pixels per image and row width of x, row width of the product
+    int x_hw, x_w, y_w;     // stride 2 and 3x3: pixels per image and row width of x, row width of the product
+    int x_h, cin, stride, dil;   // 3x3 only: rows of x, its channels (K = 9 cin), stride (1 | 2) and dilation
     int tiles_m, tiles_n;   // per image
     unsigned total_tiles;
     int relu;
@@ -105,12 +106,48 @@ __device__ __forceinline__ half2_t bn_tail_pair(half2_t x, half2_t r, const BnCh
     return v;
 }
 
-// S2: the convolution has stride 2 - the product's pixel (y, x) is x's pixel (2y, 2x): a piece of 8 product pixels
+// XMODE kXStride2: the convolution has stride 2 - the product's pixel (y, x) is x's pixel (2y, 2x): a piece of 8 product pixels
 // is the even elements of 16 consecutive pixels of x (two 16-byte loads).
 // PRE: x is the raw result of the convolution before; its batch-norm and ReLU (per input channel = per row of the X
 // tile) are applied to the pieces on their way from the staging registers into LDS, rounded to fp16 as the separate
 // batch-norm launch stores them: that launch, its read of x and its write of the activated tensor are gone.
-template <bool A_VEC, int STAGES, int MT, bool S2 = false, bool PRE = false>
+//
+// X3: a 3x3 convolution (padding = dilation) as nine shifted 1x1 products in one sum: W comes as [Cout][9][Cin]
+// (K = 9 Cin, row kk = tap * Cin + channel), and row kk of the X tile is channel kk % Cin of x read at the tap's offset:
+// with stride 1 one 16-byte load from an address that is only 2-byte aligned (started inside the row at the image's
+// left and right edge and shifted in registers, zeros coming in), with stride 2 eight single halfs; rows of x above
+// and below the image are zeros.
+constexpr int kXPlain = 0, kXStride2 = 1, kX3x3 = 2;
+typedef u32x4_t u32x4_any_t __attribute__((aligned(2)));   // a 16-byte load from a 2-byte aligned address
+
+// v's eight halfs moved up by n elements (n > 0: zeros enter at element 0) or down by -n (zeros enter at element 7)
+__device__ __forceinline__ uint4 mm_shift_halfs(uint4 v, int n) {
+    unsigned long long lo = (static_cast<unsigned long long>(v.y) << 32) | v.x;
+    unsigned long long hi = (static_cast<unsigned long long>(v.w) << 32) | v.z;
+    if (n > 0) {
+        const int b = 16 * n;
+        if (b >= 64) {
+            hi = b >= 128 ? 0ull : lo << (b - 64);
+            lo = 0ull;
+        } else {
+            hi = (hi << b) | (lo >> (64 - b));
+            lo <<= b;
+        }
+    } else if (n < 0) {
+        const int b = -16 * n;
+        if (b >= 64) {
+            lo = b >= 128 ? 0ull : hi >> (b - 64);
+            hi = 0ull;
+        } else {
+            lo = (lo >> b) | (hi << (64 - b));
+            hi >>= b;
+        }
+    }
+    return make_uint4(static_cast<unsigned>(lo), static_cast<unsigned>(lo >> 32), static_cast<unsigned>(hi),
+                      static_cast<unsigned>(hi >> 32));
+}
+
+template <bool A_VEC, int STAGES, int MT, int XMODE = kXPlain, bool PRE = false>
 __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void conv1x1_bn_act_mfma_kernel(MmArgs a) {
     constexpr int BM = kMmBM * MT;          // channels per workgroup: MT 32-channel product tiles per wave
     constexpr int A_PIECES = 4 * MT;        // 16-byte pieces of A per lane and K step
@@ -143,14 +180,28 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
     const bool has_bn = a.mean != nullptr, has_res = a.res != nullptr, res_bn = a.r_mean != nullptr;
     uint4 rres[ROWS];
 
-    const size_t x_plane = S2 ? static_cast<size_t>(a.x_hw) : static_cast<size_t>(a.hw);
-    const _Float16 *xi = a.x + img * static_cast<size_t>(a.K) * x_plane;
+    const size_t x_plane = XMODE != kXPlain ? static_cast<size_t>(a.x_hw) : static_cast<size_t>(a.hw);
+    const _Float16 *xi = a.x + img * static_cast<size_t>(XMODE == kX3x3 ? a.cin : a.K) * x_plane;
     // the lane's piece of an X row: pixels n0 + 8 (tid & 7) .. +7 of the product (the same piece in every K step)
     const int b_p = n0 + (tid & 7) * 8;
     size_t b_src = static_cast<size_t>(b_p);
-    if constexpr (S2) {
-        const int yo = b_p / a.y_w, xo = b_p - yo * a.y_w;   // a piece lies inside one row: y_w is a multiple of 8
-        b_src = static_cast<size_t>(2 * yo) * a.x_w + 2 * xo;
+    int b_yo = 0, b_xo = 0;   // the piece's row and first column in the product (a piece lies inside one row: y_w % 8 == 0)
+    if constexpr (XMODE != kXPlain) {
+        b_yo = b_p / a.y_w;
+        b_xo = b_p - b_yo * a.y_w;
+        b_src = static_cast<size_t>(2 * b_yo) * a.x_w + 2 * b_xo;
+    }
+
+    // 3x3: (tap, channel) of the lane's two X rows of the NEXT K step to be loaded; load_step is called for K steps in
+    // ascending order, one call per step, and moves them on
+    int x3_tap[2] = {0, 0}, x3_ci[2] = {0, 0};
+    if constexpr (XMODE == kX3x3) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kk = (tid + kMmThreads * i) >> 3;
+            x3_tap[i] = kk / a.cin;
+            x3_ci[i] = kk - x3_tap[i] * a.cin;
+        }
     }
 
     // global -> register staging per K step: A_PIECES 16-byte pieces of A and two of B per lane
@@ -179,9 +230,56 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
             const int c = tid + kMmThreads * i;
             const int kk = k0 + (c >> 3);
             rb[i] = make_uint4(0, 0, 0, 0);
-            if (kk < a.K && b_p < a.hw) {   // hw is a multiple of 8: a piece is inside the row or outside it
+            if constexpr (XMODE == kX3x3) {
+                if (kk < a.K && b_p < a.hw) {
+                    const int tap = x3_tap[i], ci = x3_ci[i];   // kk = tap * cin + ci, kept up to date below
+                    const int ty = tap / 3, dy = ty - 1, dx = tap - 3 * ty - 1;
+                    const int iy = b_yo * a.stride + dy * a.dil;
+                    if (iy >= 0 && iy < a.x_h) {
+                        const _Float16 *row = xi + static_cast<size_t>(ci) * x_plane + static_cast<size_t>(iy) * a.x_w;
+                        if (a.stride == 1) {
+                            const int ix0 = b_xo + dx * a.dil;
+                            const int start = min(max(ix0, 0), a.x_w - 8);
+                            const u32x4_t raw = *reinterpret_cast<const u32x4_any_t *>(row + start);
+                            const uint4 v = make_uint4(raw.x, raw.y, raw.z, raw.w);
+                            rb[i] = start == ix0 ? v : mm_shift_halfs(v, start - ix0);
+                        } else if (a.dil == 1) {
+                            // columns 2 (xo + e) + dx of the 16 from 2 xo on: their even halfs (dx = 0), their odd halfs
+                            // (dx = +1), or the column before them and the first seven odd halfs (dx = -1)
+                            const _Float16 *src = row + 2 * b_xo;
+                            const uint4 lo = *reinterpret_cast<const uint4 *>(src), hi = *reinterpret_cast<const uint4 *>(src + 8);
+                            if (dx == 0) {
+                                rb[i] = make_uint4((lo.x & 0xffffu) | (lo.y << 16), (lo.z & 0xffffu) | (lo.w << 16),
+                                                   (hi.x & 0xffffu) | (hi.y << 16), (hi.z & 0xffffu) | (hi.w << 16));
+                            } else {
+                                uint4 odd = make_uint4((lo.x >> 16) | (lo.y & 0xffff0000u), (lo.z >> 16) | (lo.w & 0xffff0000u),
+                                                       (hi.x >> 16) | (hi.y & 0xffff0000u), (hi.z >> 16) | (hi.w & 0xffff0000u));
+                                if (dx < 0) {
+                                    odd = mm_shift_halfs(odd, 1);
+                                    if (b_xo > 0) odd.x |= static_cast<unsigned>(__builtin_bit_cast(unsigned short, src[-1]));
+                                }
+                                rb[i] = odd;
+                            }
+                        } else {
+                            half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const int ix = (b_xo + e) * a.stride + dx * a.dil;
+                                if (ix >= 0 && ix < a.x_w) v[e] = row[ix];
+                            }
+                            rb[i] = __builtin_bit_cast(uint4, v);
+                        }
+                    }
+                }
+                // the next call is for the K step after this one: rows 64 further on
+                x3_ci[i] += kMmBK;
+                while (x3_ci[i] >= a.cin) {
+                    x3_ci[i] -= a.cin;
+                    ++x3_tap[i];
+                }
+            } else if (kk < a.K && b_p < a.hw) {   // hw is a multiple of 8: a piece is inside the row or outside it
                 const _Float16 *src = xi + static_cast<size_t>(kk) * x_plane + b_src;
-                if constexpr (S2) {
+                if constexpr (XMODE == kXStride2) {
                     const uint4 lo = *reinterpret_cast<const uint4 *>(src), hi = *reinterpret_cast<const uint4 *>(src + 8);
                     rb[i] = make_uint4((lo.x & 0xffffu) | (lo.y << 16), (lo.z & 0xffffu) | (lo.w << 16),
                                        (hi.x & 0xffffu) | (hi.y << 16), (hi.z & 0xffffu) | (hi.w << 16));
@@ -364,8 +462,11 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
                           const float *r_var, const float *r_weight, const float *r_bias, float r_eps,
                           int32_t relu, int64_t y_image_stride, int32_t x_h, int32_t x_w, const float *p_mean,
                           const float *p_var, const float *p_weight, const float *p_bias, float p_eps, int32_t p_relu,
-                          void *stream) {
+                          int32_t c3_stride, int32_t c3_dil, void *stream) {
+    // c3_stride > 0: a 3x3 convolution of that stride and dilation c3_dil over x [n, cin, x_h, x_w]; weight is [cout][9][cin]
     using namespace spice;
+    const bool c3 = c3_stride > 0;
+    const int64_t kdim = c3 ? 9 * cin : cin;   // length of the sums
     if (n < 0 || cin <= 0 || hw < 0 || cout <= 0) return SPICE_ERR_ARG;
     if (n == 0 || hw == 0) return SPICE_OK;
     if (x == nullptr || weight == nullptr || y == nullptr) return SPICE_ERR_ARG;
@@ -374,7 +475,7 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     if (r_mean != nullptr && (residual == nullptr || r_var == nullptr || r_weight == nullptr || r_bias == nullptr))
         return SPICE_ERR_ARG;
     if (p_mean != nullptr && (p_var == nullptr || p_weight == nullptr || p_bias == nullptr)) return SPICE_ERR_ARG;
-    if (p_mean != nullptr && (cin > kMmPreMaxK || x_h > 0)) return SPICE_ERR_UNSUPPORTED;
+    if (p_mean != nullptr && (cin > kMmPreMaxK || x_h > 0 || c3)) return SPICE_ERR_UNSUPPORTED;
     // 16-byte pieces of whole rows of X, R and Y: the plane size must be a multiple of 8 halfs
     if (y_image_stride == 0) y_image_stride = cout * hw;   // dense
     if (y_image_stride < cout * hw) return SPICE_ERR_ARG;
@@ -386,7 +487,7 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     // option (SPICE_CONV1X1_MT=2), not the default: at 206 registers a compute unit holds two workgroups instead of
     // four, which on MI355X costs more than the traffic saves on every pair of the DeepLabV3+-ResNet-50 forward
     // but one (tools/conv1x1_bench.py: 958 us per forward against 850 us)
-    const bool wide = mm_mt_knob() >= 2 && cout > kMmBM && x_h == 0 && p_mean == nullptr;
+    const bool wide = mm_mt_knob() >= 2 && cout > kMmBM && x_h == 0 && p_mean == nullptr && !c3;
     const int64_t tiles_m = ceil_div(cout, wide ? 2 * kMmBM : kMmBM);
     if (tiles_m * tiles_n > INT32_MAX / n) return SPICE_ERR_UNSUPPORTED;
     MmArgs a;
@@ -412,12 +513,16 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     a.p_eps = p_eps;
     a.p_relu = p_relu ? 1 : 0;
     a.M = static_cast<int>(cout);
-    a.K = static_cast<int>(cin);
+    a.K = static_cast<int>(kdim);
     a.hw = static_cast<int>(hw);
-    const bool s2 = x_h > 0;
-    a.x_hw = s2 ? x_h * x_w : 0;
+    const bool s2 = x_h > 0 && !c3;
+    a.x_hw = x_h > 0 ? x_h * x_w : 0;
     a.x_w = x_w;
-    a.y_w = s2 ? x_w / 2 : 0;
+    a.y_w = s2 ? x_w / 2 : (c3 ? x_w / c3_stride : 0);
+    a.x_h = x_h;
+    a.cin = static_cast<int>(cin);
+    a.stride = c3_stride;
+    a.dil = c3_dil;
     a.tiles_m = static_cast<int>(tiles_m);
     a.tiles_n = static_cast<int>(tiles_n);
     a.total_tiles = static_cast<unsigned>(tiles_m * tiles_n * n);
@@ -427,12 +532,18 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     // deep K on a grid that leaves a compute unit one or two workgroups: keep three K steps in flight
     const long forced = mm_stages_knob();
     const bool deep = !wide && (forced > 0 ? forced >= 3
-                                           : (cin >= 4 * kMmBK && static_cast<int64_t>(a.total_tiles) <= 2 * static_cast<int64_t>(device_cu_count())));
-    const bool vec = (cin & 7) == 0 && aligned16(weight);
+                                           : (kdim >= 4 * kMmBK && static_cast<int64_t>(a.total_tiles) <= 2 * static_cast<int64_t>(device_cu_count())));
+    const bool vec = (kdim & 7) == 0 && aligned16(weight);
 #define SPICE_MM_LAUNCH(V, S, T) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, T>), grid, block, 0, st, a)
-#define SPICE_MM_LAUNCH_S2(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, true>), grid, block, 0, st, a)
-#define SPICE_MM_LAUNCH_PRE(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, false, true>), grid, block, 0, st, a)
-    if (p_mean != nullptr) {
+#define SPICE_MM_LAUNCH_S2(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, kXStride2>), grid, block, 0, st, a)
+#define SPICE_MM_LAUNCH_X3(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, kX3x3>), grid, block, 0, st, a)
+#define SPICE_MM_LAUNCH_PRE(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, kXPlain, true>), grid, block, 0, st, a)
+    if (c3) {
+        if (deep && vec) SPICE_MM_LAUNCH_X3(true, 3);
+        else if (deep) SPICE_MM_LAUNCH_X3(false, 3);
+        else if (vec) SPICE_MM_LAUNCH_X3(true, 1);
+        else SPICE_MM_LAUNCH_X3(false, 1);
+    } else if (p_mean != nullptr) {
         if (deep && vec) SPICE_MM_LAUNCH_PRE(true, 3);
         else if (deep) SPICE_MM_LAUNCH_PRE(false, 3);
         else if (vec) SPICE_MM_LAUNCH_PRE(true, 1);
@@ -454,6 +565,7 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     }
 #undef SPICE_MM_LAUNCH
 #undef SPICE_MM_LAUNCH_S2
+#undef SPICE_MM_LAUNCH_X3
 #undef SPICE_MM_LAUNCH_PRE
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;
@@ -468,7 +580,7 @@ extern "C" int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void 
                                         void *stream) {
     return conv1x1_launch(x, weight, y, n, cin, hw, cout, mean, var, bn_weight, bn_bias, eps, residual, r_mean, r_var,
                           r_weight, r_bias, r_eps, relu, y_image_stride, 0, 0, p_mean, p_var, p_weight, p_bias, p_eps, p_relu,
-                          stream);
+                          0, 0, stream);
 }
 
 extern "C" int spice_conv1x1_stride2_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int32_t h,
@@ -478,5 +590,19 @@ extern "C" int spice_conv1x1_stride2_f16(const void *x, const void *weight, void
     if ((h & 1) || (w & 15)) return SPICE_ERR_UNSUPPORTED;
     return conv1x1_launch(x, weight, y, n, cin, static_cast<int64_t>(h / 2) * (w / 2), cout, nullptr, nullptr, nullptr,
                           nullptr, 0.0f, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, 0, 0, h, w, nullptr, nullptr, nullptr,
-                          nullptr, 0.0f, 0, stream);
+                          nullptr, 0.0f, 0, 0, 0, stream);
+}
+
+extern "C" int spice_conv3x3_bn_act_f16(const void *x, const void *weight9, void *y, int64_t n, int64_t cin, int32_t h,
+                                        int32_t w, int64_t cout, int32_t stride, int32_t dilation, const float *mean,
+                                        const float *var, const float *bn_weight, const float *bn_bias, float eps,
+                                        int32_t relu, void *stream) {
+    if (h <= 0 || w <= 0) return SPICE_ERR_ARG;
+    if ((stride != 1 && stride != 2) || dilation < 1 || dilation > 7) return SPICE_ERR_UNSUPPORTED;
+    // whole stride cells; rows of the result that are whole 16-byte pieces; the in-row start of an edge load needs 8 columns
+    if (h % stride != 0 || w % stride != 0 || ((w / stride) & 7) != 0 || w < 8) return SPICE_ERR_UNSUPPORTED;
+    if (cin > (1 << 16)) return SPICE_ERR_UNSUPPORTED;
+    return conv1x1_launch(x, weight9, y, n, cin, static_cast<int64_t>(h / stride) * (w / stride), cout, mean, var, bn_weight,
+                          bn_bias, eps, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, relu, 0, h, w, nullptr, nullptr,
+                          nullptr, nullptr, 0.0f, 0, stride, dilation, stream);
 }

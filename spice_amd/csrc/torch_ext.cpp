@@ -567,6 +567,35 @@ Tensor conv1x1_bn_act(const Tensor &x, const Tensor &weight2d, const Tensor &mea
     return t;
 }
 
+// relu?( bn( conv2d(x, weight, stride, padding = dilation, dilation) ) ) for a 3x3 convolution; weight9 is the weight as
+// [Cout, 9 * Cin], tap-major.  One launch of the matrix-core kernel.
+Tensor conv3x3_bn_act(const Tensor &x, const Tensor &weight9, const Tensor &mean, const Tensor &var, const Tensor &weight,
+                      const Tensor &bias, double eps, bool relu, int64_t stride, int64_t dilation) {
+    TORCH_CHECK_TYPE(x.scalar_type() == at::kHalf && weight9.scalar_type() == at::kHalf,
+                     "conv3x3_bn_act: x and weight must be fp16");
+    TORCH_CHECK(x.is_cuda(), "x is on ", x.device(),
+                "; the MI355X path has no CPU implementation (move the tensor to a HIP device)");
+    TORCH_CHECK(weight9.device() == x.device(), "conv3x3_bn_act: weight must be on x's device");
+    TORCH_CHECK_VALUE(x.dim() == 4 && weight9.dim() == 2 && weight9.size(1) == 9 * x.size(1) && x.is_contiguous() &&
+                          weight9.is_contiguous(),
+                      "conv3x3_bn_act: x must be contiguous [N,Cin,H,W] and weight contiguous [Cout, 9*Cin]");
+    TORCH_CHECK_VALUE((stride == 1 || stride == 2) && dilation >= 1, "conv3x3_bn_act: stride 1 or 2, dilation >= 1");
+    const int64_t n = x.size(0), cin = x.size(1), h = x.size(2), w = x.size(3), c = weight9.size(0);
+    for (const Tensor *p : {&mean, &var, &weight, &bias})
+        TORCH_CHECK_TYPE(p->scalar_type() == at::kFloat && p->device() == x.device() && p->numel() == c && p->is_contiguous(),
+                         "conv3x3_bn_act: the four parameter vectors must be contiguous fp32 [", c, "] on ", x.device());
+    TORCH_CHECK_VALUE(h % stride == 0 && w % stride == 0, "conv3x3_bn_act: the plane must be whole stride cells");
+    c10::DeviceGuard guard(x.device());
+    Tensor out = at::empty({n, c, h / stride, w / stride}, x.options());
+    if (out.numel() != 0)
+        check_rc(spice_conv3x3_bn_act_f16(x.data_ptr(), weight9.data_ptr(), out.data_ptr(), n, cin, (int32_t)h, (int32_t)w, c,
+                                          (int32_t)stride, (int32_t)dilation, mean.data_ptr<float>(), var.data_ptr<float>(),
+                                          weight.data_ptr<float>(), bias.data_ptr<float>(), (float)eps, relu ? 1 : 0,
+                                          current_stream(x)),
+                 "spice_conv3x3_bn_act_f16");
+    return out;
+}
+
 int64_t abi_version() { return spice_abi_version(); }
 
 }  // namespace
@@ -599,6 +628,8 @@ TORCH_LIBRARY(spice, m) {
           "bool want_full) -> (Tensor, Tensor)", &bn_act_maxpool);
     m.def("depthwise_conv3x3(Tensor x, Tensor weight, int dilation) -> Tensor", &depthwise_conv3x3);
     m.def("conv1x1_f16(Tensor x, Tensor weight2d, int stride) -> Tensor", &conv1x1_f16);
+    m.def("conv3x3_bn_act(Tensor x, Tensor weight9, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, "
+          "bool relu, int stride, int dilation) -> Tensor", &conv3x3_bn_act);
     m.def("conv1x1_bn_act(Tensor x, Tensor weight2d, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, "
           "Tensor? residual, Tensor? r_mean, Tensor? r_var, Tensor? r_weight, Tensor? r_bias, float r_eps, bool relu, "
           "int route, Tensor(a!)? out, Tensor? p_mean, Tensor? p_var, Tensor? p_weight, Tensor? p_bias, float p_eps, "

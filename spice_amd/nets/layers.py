@@ -210,6 +210,49 @@ def conv1x1_bn(conv: Conv1x1, bn: BatchNormAct2d, x, residual=None, residual_nor
     return _into(out, bn(conv(x), residual, residual_norm))
 
 
+# fp16 tap-major copies of 3x3 convolution weights, [Cout, 9 * Cin], kept like _FP16_WEIGHTS
+_FP16_TAPS = {}
+
+
+def _fp16_taps(weight: torch.Tensor) -> torch.Tensor:
+    key = id(weight)
+    ent = _FP16_TAPS.get(key)
+    if ent is None or ent[0]() is not weight or ent[1] != weight._version:
+        w9 = weight.detach().to(torch.float16).permute(0, 2, 3, 1).reshape(weight.shape[0], 9 * weight.shape[1]).contiguous()
+        ent = (weakref.ref(weight, lambda _, k=key: _FP16_TAPS.pop(k, None)), weight._version, w9)
+        _FP16_TAPS[key] = ent
+    return ent[2]
+
+
+# SPICE_CONV3X3=0 keeps the 3x3 convolutions with MIOpen (A/B measurements)
+_LIBRARY_CONV3X3 = os.environ.get("SPICE_CONV3X3", "1") != "0"
+
+
+def conv3x3_served_by_library(conv: nn.Conv2d, x_dtype: torch.dtype, height: int, width: int) -> bool:
+    """Whether conv3x3_bn takes this convolution on a plane of this size (then no MIOpen call, no solver lookup)."""
+    s, d = conv.stride[0], conv.dilation[0]
+    return (_LIBRARY_FORWARD and _LIBRARY_CONV3X3 and type(conv) is nn.Conv2d and conv.kernel_size == (3, 3)
+            and conv.stride == (s, s) and s in (1, 2) and conv.dilation == (d, d) and 1 <= d <= 7 and conv.padding == (d, d)
+            and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros"
+            and (x_dtype == torch.float16 or
+                 (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16))
+            and height % s == 0 and width % s == 0 and (width // s) % 8 == 0 and width >= 8)
+
+
+def conv3x3_bn(conv: nn.Conv2d, bn: BatchNormAct2d, x):
+    """bn(conv(x)) for a 3x3 convolution and the batch-norm (+ ReLU) behind it as ONE launch of the library's
+    matrix-core kernel, on the inference path of a HIP device; None where that does not apply (hooks, tracing,
+    training, other shapes), for the caller to run the modules."""
+    if (isinstance(x, torch.Tensor) and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4
+            and not torch.nn.modules.module._global_forward_hooks and not (_hooked(conv) or _hooked(bn))
+            and _plain_inference_norm(bn) and conv3x3_served_by_library(conv, x.dtype, x.shape[2], x.shape[3])):
+        if x.dtype != torch.float16:
+            x = x.to(torch.float16)   # what autocast does to a convolution's input
+        if x.is_contiguous():
+            return ops.conv3x3_bn_act(x, _fp16_taps(conv.weight), bn, bn.relu_after, conv.stride[0], conv.dilation[0])
+    return None
+
+
 class ConvBnAct(nn.Sequential):
     """Sequential(convolution, BatchNormAct2d); a 1x1 convolution and its batch-norm go through conv1x1_bn."""
 
@@ -222,4 +265,8 @@ class ConvBnAct(nn.Sequential):
             return conv1x1_bn(conv, self[1], x, out=out)
         if isinstance(conv, nn.Sequential) and len(conv) == 2 and type(conv[1]) is Conv1x1:
             return conv1x1_bn(conv[1], self[1], conv[0](x), out=out)   # separable: depthwise, then the pointwise pair
+        if type(conv) is nn.Conv2d and conv.kernel_size == (3, 3):
+            y = conv3x3_bn(conv, self[1], x)   # None where the library's 3x3 kernel does not apply
+            if y is not None:
+                return _into(out, y)
         return _into(out, self[1](conv(x)))

@@ -509,3 +509,25 @@ def conv1x1_bn_act(x: torch.Tensor, weight2d: torch.Tensor, bn: "torch.nn.BatchN
                                                               pre_bn.bias, pre_bn.eps)
     return _conv1x1_bn_fn(x, weight2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, residual, *r, relu,
                           route, out, *p, pre_relu)
+
+
+def conv3x3_supported(x: torch.Tensor, stride: int, dilation: int) -> bool:
+    """Whether conv3x3_bn_act takes this input: contiguous fp16 NCHW, the plane whole stride cells, rows of the result
+    whole 16-byte pieces."""
+    return (x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float16 and stride in (1, 2) and 1 <= dilation <= 7
+            and x.shape[2] % stride == 0 and x.shape[3] % stride == 0 and (x.shape[3] // stride) % 8 == 0
+            and x.shape[3] >= 8 and x.shape[1] <= 65536)
+
+
+_conv3x3_fn = None
+
+
+def conv3x3_bn_act(x: torch.Tensor, weight9: torch.Tensor, bn: "torch.nn.BatchNorm2d", relu: bool = False,
+                   stride: int = 1, dilation: int = 1) -> torch.Tensor:
+    """relu?(bn(conv2d(x, W, stride, padding=dilation, dilation))) for a 3x3 convolution without bias, fp16 NCHW, in ONE
+    launch of the matrix-core kernel (nine shifted 1x1 products in one fp32 sum).  weight9: W as [Cout, 9 * Cin],
+    tap-major (W.permute(0, 2, 3, 1)), fp16."""
+    global _conv3x3_fn
+    if _conv3x3_fn is None:
+        _conv3x3_fn = spice_ops().conv3x3_bn_act
+    return _conv3x3_fn(x, weight9, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, relu, stride, dilation)

@@ -30,7 +30,7 @@ from . import dist as sdist
 from . import ops
 from .engine import MagnitudeImportance, MagnitudePruner
 from .engine.pruner import SliceJob
-from .nets.layers import Conv1x1
+from .nets.layers import Conv1x1, conv3x3_served_by_library
 
 DEFAULT_RATIOS = (0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9)
 
@@ -217,6 +217,8 @@ class SensitivitySweep:
                 continue
             if isinstance(mod, Conv1x1) and mod.served_by_library(self.autocast_dtype or in_dtype, h, w):
                 continue  # a plain matrix product: no solver lookup to get out of the way
+            if conv3x3_served_by_library(mod, self.autocast_dtype or in_dtype, h, w):
+                continue  # the library's own 3x3 kernel (the bottlenecks' convolutions): likewise
             self._warmed.add(key)
             dt = self.autocast_dtype or in_dtype
             x = torch.empty(n, cin, h, w, device=self.device, dtype=dt)

@@ -1,0 +1,108 @@
+"""The 3x3 convolution + batch-norm (+ ReLU) in one launch of the matrix-core kernel (spice_conv3x3_bn_act_f16): nine
+shifted 1x1 products in one sum.  On integer-valued fp16 data every product and partial sum is exact, so the result
+must equal an exact convolution followed by the batch-norm launch BIT FOR BIT (this pins the tap order of the weights,
+the shifts, the image edges, stride and dilation).  On random data: within an fp16 step of fp64 sums and of torch's
+device convolution (MIOpen)."""
+import pytest
+import torch
+
+from spice_amd import _native as nat
+from spice_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    nat.lib()
+    return torch.device("cuda:0")
+
+
+def _norm(c, g, dev):
+    bn = torch.nn.BatchNorm2d(c).eval()
+    bn.running_mean.copy_(torch.randn(c, generator=g))
+    bn.running_var.copy_(torch.rand(c, generator=g) * 2 + 0.05)
+    bn.weight.data.copy_(torch.rand(c, generator=g) + 0.5)
+    bn.bias.data.copy_(torch.randn(c, generator=g))
+    return bn.to(dev)
+
+
+def _taps(w):
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+# n, cin, h, w, cout, stride, dilation
+CASES = [(2, 16, 8, 16, 24, 1, 1), (1, 64, 16, 16, 64, 1, 1), (1, 40, 8, 8, 130, 1, 1), (3, 23, 4, 8, 7, 1, 1),
+         (2, 32, 16, 16, 48, 1, 2), (1, 8, 8, 24, 5, 1, 3), (1, 16, 8, 8, 16, 1, 7), (2, 16, 8, 16, 24, 2, 1),
+         (1, 64, 32, 32, 64, 2, 1), (2, 21, 6, 32, 9, 2, 1), (4, 64, 64, 64, 64, 1, 1), (2, 256, 32, 32, 256, 1, 1),
+         (1, 128, 16, 16, 300, 1, 2)]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv3x3_exact_on_integer_data(dev, case, relu):
+    n, cin, h, w, cout, stride, dil = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randint(-3, 4, (n, cin, h, w), generator=g).half()
+    wt = torch.randint(-2, 3, (cout, cin, 3, 3), generator=g).half()
+    exact = torch.nn.functional.conv2d(x.double(), wt.double(), None, stride, dil, dil).half().contiguous().to(dev)
+    bn = _norm(cout, g, dev)
+    with torch.no_grad():
+        got = ops.conv3x3_bn_act(x.to(dev), _taps(wt).to(dev), bn, relu, stride, dil)
+        want = ops.bn_act(exact, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, relu=relu)
+    assert got.shape == want.shape and got.dtype == torch.float16
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 32, 32, 64, 1, 1), (2, 128, 32, 64, 128, 2, 1), (1, 256, 32, 32, 512, 1, 2),
+                                  (8, 64, 128, 128, 64, 1, 1)])
+def test_conv3x3_on_random_data(dev, case):
+    n, cin, h, w, cout, stride, dil = case
+    g = torch.Generator().manual_seed(sum(case) + 3)
+    x = torch.randn(n, cin, h, w, generator=g).half().to(dev)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).half().to(dev)
+    bn = torch.nn.BatchNorm2d(cout).eval().to(dev)   # identity statistics: the product itself, up to bn's own rounding
+    with torch.no_grad():
+        got = ops.conv3x3_bn_act(x, _taps(wt), bn, False, stride, dil)
+        there = torch.nn.functional.conv2d(x, wt, None, stride, dil, dil)
+        exact = torch.nn.functional.conv2d(x.double(), wt.double(), None, stride, dil, dil)
+    scale = float(exact.abs().max())
+    assert float((got.double() - exact).abs().max()) <= 2.0 ** -9 * scale + 1e-6
+    assert float((got.float() - there.float()).abs().max()) <= 2.0 ** -8 * scale + 1e-6
+
+
+def test_conv3x3_limits_and_bottleneck(dev):
+    g = torch.Generator().manual_seed(1)
+    bn = _norm(8, g, dev)
+    wt = torch.randn(8, 4, 3, 3, generator=g).half().to(dev)
+    x = torch.randn(1, 4, 8, 12, generator=g).half().to(dev)      # 12 columns: rows are not whole 16-byte pieces
+    assert not ops.conv3x3_supported(x, 1, 1) and ops.conv3x3_supported(x[..., :8].contiguous(), 1, 1)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError):
+            ops.conv3x3_bn_act(x, _taps(wt), bn, True, 1, 1)
+        with pytest.raises(TypeError):
+            ops.conv3x3_bn_act(x.float(), _taps(wt), bn, True, 1, 1)
+        with pytest.raises(ValueError):
+            ops.conv3x3_bn_act(x, _taps(wt)[:, :27].contiguous(), bn, True, 1, 1)
+        with pytest.raises(ValueError):
+            ops.conv3x3_bn_act(x, _taps(wt), bn, True, 3, 1)
+        assert ops.conv3x3_bn_act(x[:0, :, :, :8].contiguous(), _taps(wt), bn, True, 1, 1).shape == (0, 8, 8, 8)
+    # a bottleneck with its 3x3 convolution on the library's kernel against the same block on torch's route (a hook on
+    # conv2 sends it there): MIOpen sums in another order (Winograd), hence a few fp16 steps
+    from spice_amd.nets.resnet import Bottleneck
+    torch.manual_seed(6)
+    for stride, dilation in ((1, 1), (2, 1), (1, 2)):
+        blk = Bottleneck(64, 16, stride=stride, dilation=dilation, downsample=True).to(dev).eval()
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0.0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+        xin = torch.randn(2, 64, 16, 32, device=dev)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            a = blk(xin)
+            handle = blk.conv2.register_forward_hook(lambda m, i, o: None)
+            b = blk(xin)
+            handle.remove()
+        assert a.shape == b.shape
+        assert float((a.float() - b.float()).abs().max()) <= 2.0 ** -7 * float(b.float().abs().max())

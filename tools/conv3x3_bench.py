@@ -1,0 +1,53 @@
+"""3x3 convolution + batch-norm + ReLU: one launch of the library's matrix-core kernel against torch's convolution
+(MIOpen) + the library's batch-norm launch, for the bottleneck convolutions of the DeepLabV3+-ResNet-50 forward on an
+8x3x512x512 batch.  Usage: python tools/conv3x3_bench.py [--iters 20]"""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from spice_amd import ops
+
+# (name, count per forward, channels, input side, stride, dilation)
+CONVS = [("layer1.x.conv2", 3, 64, 128, 1, 1), ("layer2.0.conv2", 1, 128, 128, 2, 1), ("layer2.x.conv2", 3, 128, 64, 1, 1),
+         ("layer3.0.conv2", 1, 256, 64, 2, 1), ("layer3.x.conv2", 5, 256, 32, 1, 1), ("layer4.x.conv2", 3, 512, 32, 1, 2)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=8)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    total = {"library": 0.0, "miopen_plus_bn": 0.0}
+    for name, count, c, side, stride, dil in CONVS:
+        xs = [torch.randn(args.batch, c, side, side, device=dev).half() for _ in range(4)]
+        w = (torch.randn(c, c, 3, 3, device=dev) / (9 * c) ** 0.5).half()
+        w9 = w.permute(0, 2, 3, 1).reshape(c, 9 * c).contiguous()
+        bn = torch.nn.BatchNorm2d(c).eval().to(dev)
+        out_px = args.batch * (side // stride) ** 2
+        row = {"conv": name, "count": count, "channels": c, "in": side, "stride": stride, "dilation": dil,
+               "GF": round(2 * out_px * c * c * 9 / 1e9, 1)}
+        fns = {"library": lambda i: ops.conv3x3_bn_act(xs[i % 4], w9, bn, True, stride, dil),
+               "miopen_plus_bn": lambda i: ops.bn_act(F.conv2d(xs[i % 4], w, None, stride, dil, dil), bn.running_mean,
+                                                      bn.running_var, bn.weight, bn.bias, bn.eps, relu=True)}
+        with torch.no_grad():
+            for key, fn in fns.items():
+                for i in range(3):
+                    fn(i)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for i in range(args.iters):
+                    fn(i)
+                e1.record()
+                torch.cuda.synchronize()
+                us = 1e3 * e0.elapsed_time(e1) / args.iters
+                row[key + "_us"] = round(us, 1)
+                total[key] += us * count
+        print(json.dumps(row), flush=True)
+    print(json.dumps({"per_forward_us": {k: round(v, 1) for k, v in total.items()}}))
+
+
+if __name__ == "__main__":
+    main()

@@ -71,10 +71,9 @@ __device__ __forceinline__ unsigned mm_tile_of_block(unsigned id, unsigned total
 // on eight different 32-byte bank ranges once the pieces of rows with bit 1 set are exchanged pairwise.
 __device__ __forceinline__ int mm_b_offset(int k, int piece) { return k * kMmBPitch + ((piece ^ ((k & 2) << 1)) << 3); }
 
-// STAGES: K steps whose pieces are in flight in registers ahead of the step being multiplied.  One stage leaves
-// room for four workgroups per compute unit (the others' loads hide this one's latency: the case of many tiles);
-// three stages are for deep K on few tiles, where a compute unit holds one or two workgroups and a step's
-// products take a fraction of a memory round trip.
+// STAGES: 1 = one LDS image, two barriers per K step, room for four workgroups per compute unit (the others'
+// loads hide this one's latency: the case of many tiles and short K); above 1 = two LDS images and one barrier per
+// step, for deep K on few tiles, where a compute unit holds one or two workgroups.
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
@@ -117,7 +116,8 @@ __device__ __forceinline__ half2_t bn_tail_pair(half2_t x, half2_t r, const BnCh
 // with stride 1 one 16-byte load from an address that is only 2-byte aligned (started inside the row at the image's
 // left and right edge and shifted in registers, zeros coming in), with stride 2 eight single halfs; rows of x above
 // and below the image are zeros.
-constexpr int kXPlain = 0, kXStride2 = 1, kX3x3 = 2;
+constexpr int kMmOutside = 0x40000000;   // a byte offset outside W and outside an image of x (the host keeps both below 2^30 - 2^20), and still positive after a whole K of steps is added
+constexpr int kXPlain = 0, kXStride2 = 1, kX3x3 = 2, kX3x3S2 = 3;   // 3x3 with stride 1 / stride 2
 typedef u32x4_t u32x4_any_t __attribute__((aligned(2)));   // a 16-byte load from a 2-byte aligned address
 
 // v's eight halfs moved up by n elements (n > 0: zeros enter at element 0) or down by -n (zeros enter at element 7)
@@ -148,11 +148,20 @@ __device__ __forceinline__ uint4 mm_shift_halfs(uint4 v, int n) {
 }
 
 template <bool A_VEC, int STAGES, int MT, int XMODE = kXPlain, bool PRE = false>
-__global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void conv1x1_bn_act_mfma_kernel(MmArgs a) {
+__global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, (STAGES > 1 || MT == 1) ? 4 : 2) void conv1x1_bn_act_mfma_kernel(MmArgs a) {
     constexpr int BM = kMmBM * MT;          // channels per workgroup: MT 32-channel product tiles per wave
-    constexpr int A_PIECES = 4 * MT;        // 16-byte pieces of A per lane and K step
-    constexpr int ROWS = 4 * MT;            // rows per lane in the row-major pass of the epilogue
-    __shared__ __attribute__((aligned(16))) _Float16 lds[BM * kMmAPitch + kMmBK * kMmBPitch];
+    // deep K: eight waves, a 32-channel x 32-pixel product each (twice the waves to hide each other's waits: these
+    // launches leave a compute unit one or two workgroups); otherwise four waves with 32 MT channels x 64 pixels each
+    constexpr int THREADS = STAGES > 1 ? 2 * kMmThreads : kMmThreads;
+    constexpr int NT = STAGES > 1 ? 1 : 2;                // 32-pixel blocks per wave
+    constexpr int A_PIECES = BM * 8 / THREADS;            // 16-byte pieces of A per lane and K step
+    constexpr int B_PIECES = kMmBK * 8 / THREADS;         // ... of X
+    constexpr int ROWS = BM * 8 / THREADS;                // rows per lane in the row-major pass of the epilogue
+    constexpr int RSTEP = THREADS / 8;                    // ... which lie this many rows apart
+    static_assert(STAGES == 1 || MT == 1, "the eight-wave form has one 32-channel block per wave");
+    constexpr bool DEEP = STAGES > 1;       // two LDS images: a step's products run beside the next step's stores
+    constexpr int IMG = BM * kMmAPitch + kMmBK * kMmBPitch;   // halfs of one image (A tile, then X tile)
+    __shared__ __attribute__((aligned(16))) _Float16 lds[(DEEP ? 2 : 1) * IMG];
     static_assert(kMmCPitch <= kMmAPitch, "the C image fits in the A image's storage");
     __shared__ __attribute__((aligned(16))) float pre[PRE ? kMmPreMaxK * 4 : 4];   // (mean, inv, weight, bias) per input channel
     _Float16 *As = lds;
@@ -168,55 +177,87 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     if constexpr (PRE) {   // read in store_step, behind the barrier at the top of the K loop
-        for (int k = tid; k < a.K; k += kMmThreads) {
+        for (int k = tid; k < a.K; k += THREADS) {
             const BnChannel c = bn_channel_of(a.p_mean, a.p_var, a.p_weight, a.p_bias, a.p_eps, k);
             *reinterpret_cast<float4 *>(pre + 4 * k) = make_float4(c.mean, c.inv, c.weight, c.bias);
         }
     }
 
     // the row-major pass of the epilogue: lane takes 8 consecutive pixels of one channel, ROWS such pieces
-    const int e_pc = (tid & 7) * 8, e_row = tid >> 3;   // rows e_row + 32 i
+    const int e_pc = (tid & 7) * 8, e_row = tid >> 3;   // rows e_row + RSTEP i
     const int e_p = n0 + e_pc;
     const bool has_bn = a.mean != nullptr, has_res = a.res != nullptr, res_bn = a.r_mean != nullptr;
     uint4 rres[ROWS];
 
-    const size_t x_plane = XMODE != kXPlain ? static_cast<size_t>(a.x_hw) : static_cast<size_t>(a.hw);
-    const _Float16 *xi = a.x + img * static_cast<size_t>(XMODE == kX3x3 ? a.cin : a.K) * x_plane;
+    constexpr bool IS3 = XMODE == kX3x3 || XMODE == kX3x3S2;
+    const int x_plane = XMODE != kXPlain ? a.x_hw : a.hw;   // pixels per channel of x
+    const int x_chans = IS3 ? a.cin : a.K;
+    const _Float16 *xi = a.x + img * static_cast<size_t>(x_chans) * x_plane;
+    // W, and this image of x, behind buffer descriptors: 32-bit byte offsets, and an offset outside the buffer reads
+    // zeros without touching memory - which is how rows beyond M, pixels beyond the image, channels beyond K and
+    // taps above / below the image come out as zeros (kMmOutside is outside every buffer: the host checks the sizes)
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(a.w), 0, a.M * a.K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(xi), 0, x_chans * x_plane * 2, 0x00020000);
     // the lane's piece of an X row: pixels n0 + 8 (tid & 7) .. +7 of the product (the same piece in every K step)
     const int b_p = n0 + (tid & 7) * 8;
-    size_t b_src = static_cast<size_t>(b_p);
+    const bool b_in = b_p < a.hw;   // hw is a multiple of 8: a piece is inside the image or outside it
+    int b_src = b_p;
     int b_yo = 0, b_xo = 0;   // the piece's row and first column in the product (a piece lies inside one row: y_w % 8 == 0)
     if constexpr (XMODE != kXPlain) {
         b_yo = b_p / a.y_w;
         b_xo = b_p - b_yo * a.y_w;
-        b_src = static_cast<size_t>(2 * b_yo) * a.x_w + 2 * b_xo;
+        b_src = 2 * b_yo * a.x_w + 2 * b_xo;
     }
 
-    // 3x3: (tap, channel) of the lane's two X rows of the NEXT K step to be loaded; load_step is called for K steps in
-    // ascending order, one call per step, and moves them on
-    int x3_tap[2] = {0, 0}, x3_ci[2] = {0, 0};
-    if constexpr (XMODE == kX3x3) {
+    // Byte offsets of the lane's pieces, moved on by load_step, which is called once per K step in ascending order.
+    // A: row m, columns 8 (c & 7) ..; rows beyond M stay outside.
+    int a_off[A_PIECES];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int kk = (tid + kMmThreads * i) >> 3;
+    for (int i = 0; i < A_PIECES; ++i) {
+        const int c = tid + THREADS * i;
+        const int m = m0 + (c >> 3);
+        a_off[i] = m < a.M ? (m * a.K + (c & 7) * 8) * 2 : kMmOutside;
+    }
+    // X, 1x1: channel (c >> 3) + 64 step; channels beyond K are beyond the buffer.
+    // X, 3x3: K row kk = tap * cin + ci is channel ci shifted by tap (dy, dx) * dilation; x3_chan = byte offset of the
+    // channel, x3_dy / x3_dx = the shift, x3_tap > 8 = beyond K.
+    int b_off[B_PIECES], x3_tap[B_PIECES], x3_ci[B_PIECES], x3_dy[B_PIECES], x3_dx[B_PIECES];
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) {
+        const int kk = (tid + THREADS * i) >> 3;
+        if constexpr (IS3) {
             x3_tap[i] = kk / a.cin;
             x3_ci[i] = kk - x3_tap[i] * a.cin;
+            const int ty = x3_tap[i] / 3;
+            x3_dy[i] = (ty - 1) * a.dil;
+            x3_dx[i] = (x3_tap[i] - 3 * ty - 1) * a.dil;
+            b_off[i] = x3_ci[i] * x_plane * 2;
+        } else {
+            b_off[i] = b_in ? (kk * x_plane + b_src) * 2 : kMmOutside;
         }
     }
 
-    // global -> register staging per K step: A_PIECES 16-byte pieces of A and two of B per lane
-    uint4 ra_all[STAGES][A_PIECES], rb_all[STAGES][2];
-    auto load_step = [&](int k0, uint4 (&ra)[A_PIECES], uint4 (&rb)[2]) {
+    // global -> register staging per K step: A_PIECES 16-byte pieces of A and B_PIECES of X per lane.  No load is
+    // behind a branch, so the compiler can count, at each store, how many younger loads may still be in flight, and
+    // the stages overlap; a load behind a branch makes it wait for all of them.  rb_meta (3x3): halfs by which the
+    // piece is to be shifted when stored.
+    constexpr int RS = DEEP ? 2 : 1;   // register stages: K steps whose pieces are in flight
+    uint4 ra_all[RS][A_PIECES], rb_all[RS][B_PIECES];
+    int rb_meta_all[RS][B_PIECES];
+    auto as_uint4 = [](u32x4_t v) { return make_uint4(v.x, v.y, v.z, v.w); };
+    auto load_step = [&](int k0, uint4 (&ra)[A_PIECES], uint4 (&rb)[B_PIECES], int (&rb_meta)[B_PIECES]) {
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
-            const int c = tid + kMmThreads * i;
-            const int m = m0 + (c >> 3), k = k0 + (c & 7) * 8;
-            ra[i] = make_uint4(0, 0, 0, 0);
-            if (m < a.M && k < a.K) {
-                const _Float16 *src = a.w + static_cast<size_t>(m) * a.K + k;
-                if constexpr (A_VEC) {
-                    ra[i] = *reinterpret_cast<const uint4 *>(src);
-                } else {   // rows of W that do not start on 16 bytes, or a K that ends inside the piece
+            if constexpr (A_VEC) {
+                ra[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, a_off[i] + 2 * k0, 0, 0));
+            } else {   // rows of W that do not start on 16 bytes, or a K that ends inside the piece
+                const int c = tid + THREADS * i;
+                const int m = m0 + (c >> 3), k = k0 + (c & 7) * 8;
+                ra[i] = make_uint4(0, 0, 0, 0);
+                if (m < a.M && k < a.K) {
+                    const _Float16 *src = a.w + static_cast<size_t>(m) * a.K + k;
                     half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
@@ -226,24 +267,25 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + kMmThreads * i;
-            const int kk = k0 + (c >> 3);
-            rb[i] = make_uint4(0, 0, 0, 0);
-            if constexpr (XMODE == kX3x3) {
-                if (kk < a.K && b_p < a.hw) {
-                    const int tap = x3_tap[i], ci = x3_ci[i];   // kk = tap * cin + ci, kept up to date below
-                    const int ty = tap / 3, dy = ty - 1, dx = tap - 3 * ty - 1;
-                    const int iy = b_yo * a.stride + dy * a.dil;
-                    if (iy >= 0 && iy < a.x_h) {
-                        const _Float16 *row = xi + static_cast<size_t>(ci) * x_plane + static_cast<size_t>(iy) * a.x_w;
-                        if (a.stride == 1) {
-                            const int ix0 = b_xo + dx * a.dil;
-                            const int start = min(max(ix0, 0), a.x_w - 8);
-                            const u32x4_t raw = *reinterpret_cast<const u32x4_any_t *>(row + start);
-                            const uint4 v = make_uint4(raw.x, raw.y, raw.z, raw.w);
-                            rb[i] = start == ix0 ? v : mm_shift_halfs(v, start - ix0);
-                        } else if (a.dil == 1) {
+        for (int i = 0; i < B_PIECES; ++i) {
+            rb_meta[i] = 0;
+            if constexpr (IS3) {
+                const int iy = b_yo * a.stride + x3_dy[i];
+                const bool in = b_in && x3_tap[i] < 9 && static_cast<unsigned>(iy) < static_cast<unsigned>(a.x_h);
+                if constexpr (XMODE == kX3x3) {
+                    // eight columns from ix0 on; at the row's ends the load is moved inside the row and the halfs
+                    // shifted into place when stored
+                    const int ix0 = b_xo + x3_dx[i];
+                    const int start = min(max(ix0, 0), a.x_w - 8);
+                    const int off = b_off[i] + (iy * a.x_w + start) * 2;
+                    rb[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(x_rsrc, in ? off : kMmOutside, 0, 0));
+                    rb_meta[i] = start - ix0;
+                } else {
+                    rb[i] = make_uint4(0, 0, 0, 0);
+                    if (in) {
+                        const _Float16 *row = xi + (b_off[i] >> 1) + iy * a.x_w;
+                        const int dx = x3_dx[i];
+                        if (a.dil == 1) {
                             // columns 2 (xo + e) + dx of the 16 from 2 xo on: their even halfs (dx = 0), their odd halfs
                             // (dx = +1), or the column before them and the first seven odd halfs (dx = -1)
                             const _Float16 *src = row + 2 * b_xo;
@@ -264,7 +306,7 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
                             half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
-                                const int ix = (b_xo + e) * a.stride + dx * a.dil;
+                                const int ix = (b_xo + e) * a.stride + dx;
                                 if (ix >= 0 && ix < a.x_w) v[e] = row[ix];
                             }
                             rb[i] = __builtin_bit_cast(uint4, v);
@@ -273,32 +315,49 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
                 }
                 // the next call is for the K step after this one: rows 64 further on
                 x3_ci[i] += kMmBK;
+                b_off[i] += kMmBK * x_plane * 2;
                 while (x3_ci[i] >= a.cin) {
                     x3_ci[i] -= a.cin;
+                    b_off[i] -= a.cin * x_plane * 2;
                     ++x3_tap[i];
+                    if (x3_dx[i] == a.dil) {
+                        x3_dx[i] = -a.dil;
+                        x3_dy[i] += a.dil;
+                    } else {
+                        x3_dx[i] += a.dil;
+                    }
                 }
-            } else if (kk < a.K && b_p < a.hw) {   // hw is a multiple of 8: a piece is inside the row or outside it
-                const _Float16 *src = xi + static_cast<size_t>(kk) * x_plane + b_src;
+            } else {
                 if constexpr (XMODE == kXStride2) {
-                    const uint4 lo = *reinterpret_cast<const uint4 *>(src), hi = *reinterpret_cast<const uint4 *>(src + 8);
+                    const uint4 lo = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(x_rsrc, b_off[i], 0, 0));
+                    const uint4 hi = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(x_rsrc, b_off[i] + 16, 0, 0));
                     rb[i] = make_uint4((lo.x & 0xffffu) | (lo.y << 16), (lo.z & 0xffffu) | (lo.w << 16),
                                        (hi.x & 0xffffu) | (hi.y << 16), (hi.z & 0xffffu) | (hi.w << 16));
                 } else {
-                    rb[i] = *reinterpret_cast<const uint4 *>(src);
+                    rb[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(x_rsrc, b_off[i], 0, 0));
                 }
+                b_off[i] += kMmBK * x_plane * 2;
             }
         }
     };
-    auto store_step = [&](int k0, const uint4 (&ra)[A_PIECES], const uint4 (&rb)[2]) {
+    auto store_step = [&](int k0, const uint4 (&ra)[A_PIECES], const uint4 (&rb)[B_PIECES], const int (&rb_meta)[B_PIECES], int image) {
+        const bool k_ends_inside = k0 + kMmBK > a.K;   // uniform; only the last step of a K that is no multiple of 64
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
-            const int c = tid + kMmThreads * i;
-            *reinterpret_cast<uint4 *>(As + (c >> 3) * kMmAPitch + (c & 7) * 8) = ra[i];
+            const int c = tid + THREADS * i;
+            uint4 piece = ra[i];
+            if constexpr (A_VEC) {   // columns beyond K are the next row's
+                if (k_ends_inside && k0 + (c & 7) * 8 >= a.K) piece = make_uint4(0, 0, 0, 0);
+            }
+            *reinterpret_cast<uint4 *>(As + image + (c >> 3) * kMmAPitch + (c & 7) * 8) = piece;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + kMmThreads * i;
+        for (int i = 0; i < B_PIECES; ++i) {
+            const int c = tid + THREADS * i;
             uint4 piece = rb[i];
+            if constexpr (XMODE == kX3x3) {
+                if (rb_meta[i] != 0) piece = mm_shift_halfs(piece, rb_meta[i]);
+            }
             if constexpr (PRE) {
                 const int kk = k0 + (c >> 3);
                 if (kk < a.K) {   // rows beyond K stay zero
@@ -314,21 +373,22 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
                     piece = __builtin_bit_cast(uint4, v);
                 }
             }
-            *reinterpret_cast<uint4 *>(Bs + mm_b_offset(c >> 3, c & 7)) = piece;
+            *reinterpret_cast<uint4 *>(Bs + image + mm_b_offset(c >> 3, c & 7)) = piece;
         }
     };
 
-    float16_t acc[MT][2];
+    float16_t acc[MT][NT];
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][t][r] = 0.0f;
 
     // operand addresses inside the LDS images (halfs), without the K-step part
     const int h = lane >> 5;
-    const int wave_row = 32 * MT * wave;                                  // first channel of the wave inside the tile
+    const int wave_row = 32 * MT * (wave & 3);                            // first channel of the wave inside the tile
+    const int wave_px = NT == 1 ? wave >> 2 : 0;                          // first 32-pixel block of the wave
     const int w_off = (wave_row + (lane & 31)) * kMmAPitch + 8 * h;       // + 32 mi rows + 16 s
     // transposed read: lane 4q + p of a 16-lane group supplies row q, pixels 4p .. 4p+3 of the group's 16 pixels
     const int g_b = (lane >> 4) & 1, g_q = (lane & 15) >> 2, g_p = lane & 3;
@@ -337,57 +397,85 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) has_rows[mi] = m0 + wave_row + 32 * mi < a.M;
 
-    auto multiply_step = [&]() {
+    // one K step of the products: the operands of FD sub-steps of 16 are all requested from LDS before the first
+    // product, in straight-line code, so that the reads of a sub-step overlap the products of the one before
+    constexpr int FD = (STAGES == 1 && MT == 1) ? 2 : 4;
+    auto multiply_step = [&](int image) {
+        if (!has_rows[0]) return;   // uniform per wave; rows of a later 32 beyond M are zeros in the A image
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            half8_t fw[MT], fx[2];
+        for (int s0 = 0; s0 < 4; s0 += FD) {
+            half8_t fw[FD][MT], fx[FD][NT];
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-                fw[mi] = *reinterpret_cast<const half8_t *>(As + w_off + 32 * mi * kMmAPitch + 16 * s);
+            for (int sd = 0; sd < FD; ++sd) {
+                const int s = s0 + sd;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                // pixels 32 t + 16 g_b + 4 g_p ..: piece 4 t + 2 g_b + (g_p >> 1), second half of it for odd g_p
-                const int piece = 4 * t + 2 * g_b + (g_p >> 1), within = 4 * (g_p & 1);
-                const int k_lo = 16 * s + x_row, k_hi = k_lo + 4;
-                const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(Bs + mm_b_offset(k_lo, piece) + within));
-                const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(Bs + mm_b_offset(k_hi, piece) + within));
-                const short8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                fx[t] = __builtin_bit_cast(half8_t, both);
+                for (int mi = 0; mi < MT; ++mi)
+                    fw[sd][mi] = *reinterpret_cast<const half8_t *>(As + image + w_off + 32 * mi * kMmAPitch + 16 * s);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    // pixels 32 t + 16 g_b + 4 g_p ..: piece 4 t + 2 g_b + (g_p >> 1), second half of it for odd g_p
+                    const int piece = 4 * (wave_px + t) + 2 * g_b + (g_p >> 1), within = 4 * (g_p & 1);
+                    const int k_lo = 16 * s + x_row, k_hi = k_lo + 4;
+                    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(Bs + image + mm_b_offset(k_lo, piece) + within));
+                    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(Bs + image + mm_b_offset(k_hi, piece) + within));
+                    const short8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    fx[sd][t] = __builtin_bit_cast(half8_t, both);
+                }
             }
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-                if (has_rows[mi]) {
+            for (int sd = 0; sd < FD; ++sd)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
-                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fx[t], fw[mi], acc[mi][t], 0, 0, 0);
-                }
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fx[sd][t], fw[sd][mi], acc[mi][t], 0, 0, 0);
         }
     };
 
-#pragma unroll
-    for (int st = 0; st < STAGES; ++st)
-        if (st == 0 || st * kMmBK < a.K) load_step(st * kMmBK, ra_all[st], rb_all[st]);
-    // the residual's pieces, requested after the first K steps' so that waiting for those does not wait for these
+    load_step(0, ra_all[0], rb_all[0], rb_meta_all[0]);
+    if constexpr (DEEP) load_step(kMmBK, ra_all[1], rb_all[1], rb_meta_all[1]);
+    // the residual's pieces, requested behind the first K steps'
     if (has_res) {
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-            const int m = m0 + e_row + 32 * i;
+            const int m = m0 + e_row + RSTEP * i;
             rres[i] = make_uint4(0, 0, 0, 0);
             if (m < a.M && e_p < a.hw)
                 rres[i] = *reinterpret_cast<const uint4 *>(a.res + (img * a.M + m) * static_cast<size_t>(a.hw) + e_p);
         }
     }
-    for (int k0 = 0; k0 < a.K; k0 += STAGES * kMmBK) {
-#pragma unroll
-        for (int st = 0; st < STAGES; ++st) {
-            const int k = k0 + st * kMmBK;
-            if (k < a.K) {   // uniform
-                __syncthreads();   // every wave has read the previous step's images
-                store_step(k, ra_all[st], rb_all[st]);
-                __syncthreads();
-                if (k + STAGES * kMmBK < a.K) load_step(k + STAGES * kMmBK, ra_all[st], rb_all[st]);   // in flight from here
-                multiply_step();
-            }
+    const int n_steps = (a.K + kMmBK - 1) / kMmBK;
+    if constexpr (DEEP) {
+        // Step t multiplies out of image t & 1.  Behind its products the pieces of step t + 1, requested two steps
+        // ago into register stage (t + 1) & 1, are stored into the other image (every wave left that image at the
+        // barrier before), the loads of step t + 3 go out into the stage just emptied, and ONE barrier closes the
+        // step.  Nothing in the body is conditional - loads beyond K read the operands' first bytes, stores beyond K
+        // write zeros into an image nobody reads - so the compiler counts the loads a store may leave in flight.
+        if constexpr (PRE) __syncthreads();   // the pending batch-norm's parameters are in LDS
+        store_step(0, ra_all[0], rb_all[0], rb_meta_all[0], 0);
+        load_step(2 * kMmBK, ra_all[0], rb_all[0], rb_meta_all[0]);
+        __syncthreads();
+        auto deep_step = [&](int t, auto parity) {
+            constexpr int P = decltype(parity)::value;   // t & 1
+            multiply_step(P * IMG);
+            __builtin_amdgcn_sched_barrier(0);   // the stores wait for loads: not before the products
+            store_step((t + 1) * kMmBK, ra_all[1 - P], rb_all[1 - P], rb_meta_all[1 - P], (1 - P) * IMG);
+            load_step((t + 3) * kMmBK, ra_all[1 - P], rb_all[1 - P], rb_meta_all[1 - P]);
+            __syncthreads();
+        };
+        int t = 0;
+        for (; t + 2 <= n_steps; t += 2) {
+            deep_step(t, std::integral_constant<int, 0>{});
+            deep_step(t + 1, std::integral_constant<int, 1>{});
+        }
+        if (t < n_steps) deep_step(t, std::integral_constant<int, 0>{});
+    } else {
+        for (int t = 0; t < n_steps; ++t) {
+            __syncthreads();   // every wave has read the previous step's image
+            store_step(t * kMmBK, ra_all[0], rb_all[0], rb_meta_all[0], 0);
+            __syncthreads();
+            if (t + 1 < n_steps) load_step((t + 1) * kMmBK, ra_all[0], rb_all[0], rb_meta_all[0]);   // in flight from here
+            multiply_step(0);
         }
     }
 
@@ -399,13 +487,13 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
         if (has_rows[mi]) {
             const int row = wave_row + 32 * mi + (lane & 31);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
                     half4_t v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = static_cast<_Float16>(acc[mi][t][4 * rq + e]);
-                    *reinterpret_cast<half4_t *>(Cs + row * kMmCPitch + 32 * t + 8 * rq + 4 * h) = v;
+                    *reinterpret_cast<half4_t *>(Cs + row * kMmCPitch + 32 * (wave_px + t) + 8 * rq + 4 * h) = v;
                 }
         }
     __syncthreads();
@@ -413,7 +501,7 @@ __global__ __launch_bounds__(kMmThreads, (STAGES == 1 && MT == 1) ? 4 : 2) void 
     if (e_p >= a.hw) return;
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
-        const int row = e_row + 32 * i;
+        const int row = e_row + RSTEP * i;
         const int m = m0 + row;
         if (m >= a.M) break;   // rows ascend with i
         half8_t v = *reinterpret_cast<const half8_t *>(Cs + row * kMmCPitch + e_pc);
@@ -482,6 +570,11 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     if ((hw & 7) != 0 || (y_image_stride & 7) != 0 || !aligned16(x) || !aligned16(y) || (residual != nullptr && !aligned16(residual)))
         return SPICE_ERR_UNSUPPORTED;
     if (cin > (1 << 20) || cout > (1 << 20) || hw > (1 << 28)) return SPICE_ERR_UNSUPPORTED;
+    {   // the kernel addresses W and one image of x with 32-bit byte offsets
+        const int64_t limit = (int64_t{1} << 30) - (int64_t{1} << 20);
+        const int64_t x_plane = x_h > 0 ? static_cast<int64_t>(x_h) * x_w : hw;
+        if (cout * kdim * 2 > limit || cin * x_plane * 2 > limit) return SPICE_ERR_UNSUPPORTED;
+    }
     const int64_t tiles_n = ceil_div(hw, kMmBN);
     // 256-channel tiles (two product tiles per wave: half the reads of X and of the LDS images per product) are an
     // option (SPICE_CONV1X1_MT=2), not the default: at 206 registers a compute unit holds two workgroups instead of
@@ -528,17 +621,23 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     a.total_tiles = static_cast<unsigned>(tiles_m * tiles_n * n);
     a.relu = relu ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(a.total_tiles), block(kMmThreads);
-    // deep K on a grid that leaves a compute unit one or two workgroups: keep three K steps in flight
+    const dim3 grid(a.total_tiles);
+    // deep K on a grid that leaves a compute unit one or two workgroups: the eight-wave form with two LDS images
     const long forced = mm_stages_knob();
     const bool deep = !wide && (forced > 0 ? forced >= 3
                                            : (kdim >= 4 * kMmBK && static_cast<int64_t>(a.total_tiles) <= 2 * static_cast<int64_t>(device_cu_count())));
     const bool vec = (kdim & 7) == 0 && aligned16(weight);
-#define SPICE_MM_LAUNCH(V, S, T) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, T>), grid, block, 0, st, a)
-#define SPICE_MM_LAUNCH_S2(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, kXStride2>), grid, block, 0, st, a)
-#define SPICE_MM_LAUNCH_X3(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, kX3x3>), grid, block, 0, st, a)
-#define SPICE_MM_LAUNCH_PRE(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, kXPlain, true>), grid, block, 0, st, a)
-    if (c3) {
+#define SPICE_MM_LAUNCH(V, S, T) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, T>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
+#define SPICE_MM_LAUNCH_S2(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, kXStride2>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
+#define SPICE_MM_LAUNCH_X3(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, kX3x3>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
+#define SPICE_MM_LAUNCH_X3S2(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, kX3x3S2>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
+#define SPICE_MM_LAUNCH_PRE(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, kXPlain, true>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
+    if (c3 && c3_stride == 2) {
+        if (deep && vec) SPICE_MM_LAUNCH_X3S2(true, 3);
+        else if (deep) SPICE_MM_LAUNCH_X3S2(false, 3);
+        else if (vec) SPICE_MM_LAUNCH_X3S2(true, 1);
+        else SPICE_MM_LAUNCH_X3S2(false, 1);
+    } else if (c3) {
         if (deep && vec) SPICE_MM_LAUNCH_X3(true, 3);
         else if (deep) SPICE_MM_LAUNCH_X3(false, 3);
         else if (vec) SPICE_MM_LAUNCH_X3(true, 1);
@@ -566,6 +665,7 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
 #undef SPICE_MM_LAUNCH
 #undef SPICE_MM_LAUNCH_S2
 #undef SPICE_MM_LAUNCH_X3
+#undef SPICE_MM_LAUNCH_X3S2
 #undef SPICE_MM_LAUNCH_PRE
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;

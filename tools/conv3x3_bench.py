@@ -16,11 +16,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--only", default="", help="library | miopen_plus_bn: time that side only (counter passes)")
+    ap.add_argument("--convs", default="", help="comma-separated names: those convolutions only")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     total = {"library": 0.0, "miopen_plus_bn": 0.0}
     for name, count, c, side, stride, dil in CONVS:
+        if args.convs and name not in args.convs.split(","):
+            continue
         xs = [torch.randn(args.batch, c, side, side, device=dev).half() for _ in range(4)]
         w = (torch.randn(c, c, 3, 3, device=dev) / (9 * c) ** 0.5).half()
         w9 = w.permute(0, 2, 3, 1).reshape(c, 9 * c).contiguous()
@@ -33,6 +37,8 @@ def main():
                                                       bn.running_var, bn.weight, bn.bias, bn.eps, relu=True)}
         with torch.no_grad():
             for key, fn in fns.items():
+                if args.only and key != args.only:
+                    continue
                 for i in range(3):
                     fn(i)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -384,8 +384,9 @@ int spice_conv1x1_f16(const void *x, const void *weight, void *y, int64_t n, int
  * spice_bn_act would have stored it, so that launch and its round trip through memory are gone (conv2 -> bn2 -> relu ->
  * conv3 -> bn3 of a bottleneck: one launch behind the 3x3 convolution).  Cin <= 512, else SPICE_ERR_UNSUPPORTED.
  * y_image_stride: elements between the images of y (0 = Cout * HW, dense); larger when y is a channel slice of a
- * concatenation buffer.  HW and y_image_stride must be multiples of 8 and x, y, residual 16-byte aligned, else
- * SPICE_ERR_UNSUPPORTED (callers then use the two calls above).  Holds no state and uses no scratch memory. */
+ * concatenation buffer.  HW and y_image_stride must be multiples of 8, x, y, residual 16-byte aligned, weight
+ * 4-byte aligned, and the weight matrix and one image of x below 2^30 - 2^20 bytes each (32-bit offsets inside
+ * the kernel), else SPICE_ERR_UNSUPPORTED (callers then use the two calls above).  Holds no state and uses no scratch memory. */
 int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int64_t hw,
                              int64_t cout, const float *mean, const float *var, const float *bn_weight,
                              const float *bn_bias, float eps, const void *residual, const float *r_mean,

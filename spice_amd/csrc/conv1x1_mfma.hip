@@ -26,6 +26,9 @@
 
 namespace spice {
 
+#ifndef SPICE_FD1
+#define SPICE_FD1 1
+#endif
 constexpr int kMmThreads = 256;
 constexpr int kMmBM = 128, kMmBN = 64, kMmBK = 64;
 constexpr int kMmAPitch = 72;    // halfs
@@ -147,7 +150,7 @@ __device__ __forceinline__ uint4 mm_shift_halfs(uint4 v, int n) {
                       static_cast<unsigned>(hi >> 32));
 }
 
-template <bool A_VEC, int STAGES, int MT, int XMODE = kXPlain, bool PRE = false>
+template <int STAGES, int MT, int XMODE = kXPlain, bool PRE = false, bool W_ODD = false>
 __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, (STAGES > 1 || MT == 1) ? 4 : 2) void conv1x1_bn_act_mfma_kernel(MmArgs a) {
     constexpr int BM = kMmBM * MT;          // channels per workgroup: MT 32-channel product tiles per wave
     // deep K: eight waves, a 32-channel x 32-pixel product each (twice the waves to hide each other's waits: these
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, (STAGES >
     // zeros without touching memory - which is how rows beyond M, pixels beyond the image, channels beyond K and
     // taps above / below the image come out as zeros (kMmOutside is outside every buffer: the host checks the sizes)
     const __amdgpu_buffer_rsrc_t w_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(a.w), 0, a.M * a.K * 2, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(a.w), 0, (a.M * a.K * 2 + 3) & ~3, 0x00020000);   // whole dwords: the range check is per dword
     const __amdgpu_buffer_rsrc_t x_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(xi), 0, x_chans * x_plane * 2, 0x00020000);
     // the lane's piece of an X row: pixels n0 + 8 (tid & 7) .. +7 of the product (the same piece in every K step)
@@ -250,20 +253,18 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, (STAGES >
     auto load_step = [&](int k0, uint4 (&ra)[A_PIECES], uint4 (&rb)[B_PIECES], int (&rb_meta)[B_PIECES]) {
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
-            if constexpr (A_VEC) {
-                ra[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, a_off[i] + 2 * k0, 0, 0));
-            } else {   // rows of W that do not start on 16 bytes, or a K that ends inside the piece
-                const int c = tid + THREADS * i;
-                const int m = m0 + (c >> 3), k = k0 + (c & 7) * 8;
-                ra[i] = make_uint4(0, 0, 0, 0);
-                if (m < a.M && k < a.K) {
-                    const _Float16 *src = a.w + static_cast<size_t>(m) * a.K + k;
-                    half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (k + e < a.K) v[e] = src[e];
-                    ra[i] = __builtin_bit_cast(uint4, v);
-                }
+            const int off = a_off[i] + 2 * k0;
+            if constexpr (W_ODD) {
+                // odd K: every other row of W starts in the middle of a dword.  The range check of a buffer load is
+                // per dword as addressed, so a dword that starts on W's last half would be dropped with it: read
+                // whole aligned dwords, one more than the piece, and move the bytes down
+                const u32x4_t lo = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, off & ~3, 0, 0);
+                const unsigned hi = __builtin_amdgcn_raw_buffer_load_b32(w_rsrc, (off & ~3) + 16, 0, 0);
+                const unsigned sh = static_cast<unsigned>(off) & 2u;
+                ra[i] = make_uint4(__builtin_amdgcn_alignbyte(lo.y, lo.x, sh), __builtin_amdgcn_alignbyte(lo.z, lo.y, sh),
+                                   __builtin_amdgcn_alignbyte(lo.w, lo.z, sh), __builtin_amdgcn_alignbyte(hi, lo.w, sh));
+            } else {
+                ra[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, off, 0, 0));
             }
         }
 #pragma unroll
@@ -346,8 +347,9 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, (STAGES >
         for (int i = 0; i < A_PIECES; ++i) {
             const int c = tid + THREADS * i;
             uint4 piece = ra[i];
-            if constexpr (A_VEC) {   // columns beyond K are the next row's
-                if (k_ends_inside && k0 + (c & 7) * 8 >= a.K) piece = make_uint4(0, 0, 0, 0);
+            if (k_ends_inside) {   // columns from K on are the next row's: keep the first K - k halfs
+                const int keep = a.K - (k0 + (c & 7) * 8);
+                if (keep < 8) piece = keep <= 0 ? make_uint4(0, 0, 0, 0) : mm_shift_halfs(mm_shift_halfs(piece, 8 - keep), keep - 8);
             }
             *reinterpret_cast<uint4 *>(As + image + (c >> 3) * kMmAPitch + (c & 7) * 8) = piece;
         }
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, (STAGES >
 
     // one K step of the products: the operands of FD sub-steps of 16 are all requested from LDS before the first
     // product, in straight-line code, so that the reads of a sub-step overlap the products of the one before
-    constexpr int FD = (STAGES == 1 && MT == 1) ? 2 : 4;
+    constexpr int FD = (STAGES == 1 && MT == 1) ? SPICE_FD1 : 4;
     auto multiply_step = [&](int image) {
         if (!has_rows[0]) return;   // uniform per wave; rows of a later 32 beyond M are zeros in the A image
 #pragma unroll
@@ -569,6 +571,7 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     if (y_image_stride < cout * hw) return SPICE_ERR_ARG;
     if ((hw & 7) != 0 || (y_image_stride & 7) != 0 || !aligned16(x) || !aligned16(y) || (residual != nullptr && !aligned16(residual)))
         return SPICE_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(weight) & 3u) != 0) return SPICE_ERR_UNSUPPORTED;   // the base of a buffer descriptor
     if (cin > (1 << 20) || cout > (1 << 20) || hw > (1 << 28)) return SPICE_ERR_UNSUPPORTED;
     {   // the kernel addresses W and one image of x with 32-bit byte offsets
         const int64_t limit = (int64_t{1} << 30) - (int64_t{1} << 20);
@@ -626,47 +629,43 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     const long forced = mm_stages_knob();
     const bool deep = !wide && (forced > 0 ? forced >= 3
                                            : (kdim >= 4 * kMmBK && static_cast<int64_t>(a.total_tiles) <= 2 * static_cast<int64_t>(device_cu_count())));
-    const bool vec = (kdim & 7) == 0 && aligned16(weight);
-#define SPICE_MM_LAUNCH(V, S, T) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, T>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
-#define SPICE_MM_LAUNCH_S2(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, kXStride2>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
-#define SPICE_MM_LAUNCH_X3(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, kX3x3>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
-#define SPICE_MM_LAUNCH_X3S2(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, kX3x3S2>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
-#define SPICE_MM_LAUNCH_PRE(V, S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<V, S, 1, kXPlain, true>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
-    if (c3 && c3_stride == 2) {
-        if (deep && vec) SPICE_MM_LAUNCH_X3S2(true, 3);
-        else if (deep) SPICE_MM_LAUNCH_X3S2(false, 3);
-        else if (vec) SPICE_MM_LAUNCH_X3S2(true, 1);
-        else SPICE_MM_LAUNCH_X3S2(false, 1);
+#define SPICE_MM_LAUNCH(S, T) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<S, T>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
+#define SPICE_MM_LAUNCH_S2(S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<S, 1, kXStride2>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
+#define SPICE_MM_LAUNCH_X3(S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<S, 1, kX3x3>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
+#define SPICE_MM_LAUNCH_X3S2(S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<S, 1, kX3x3S2>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
+#define SPICE_MM_LAUNCH_ODD(X, P) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<1, 1, X, P, true>), grid, dim3(kMmThreads), 0, st, a)
+#define SPICE_MM_LAUNCH_PRE(S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<S, 1, kXPlain, true>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
+    if (kdim & 1) {   // pruned to an odd number of input channels: the forms that take rows of W from the middle of a dword
+        if (c3 && c3_stride == 2) SPICE_MM_LAUNCH_ODD(kX3x3S2, false);
+        else if (c3) SPICE_MM_LAUNCH_ODD(kX3x3, false);
+        else if (p_mean != nullptr) SPICE_MM_LAUNCH_ODD(kXPlain, true);
+        else if (s2) SPICE_MM_LAUNCH_ODD(kXStride2, false);
+        else SPICE_MM_LAUNCH_ODD(kXPlain, false);
+    } else if (c3 && c3_stride == 2) {
+        if (deep) SPICE_MM_LAUNCH_X3S2(3);
+        else SPICE_MM_LAUNCH_X3S2(1);
     } else if (c3) {
-        if (deep && vec) SPICE_MM_LAUNCH_X3(true, 3);
-        else if (deep) SPICE_MM_LAUNCH_X3(false, 3);
-        else if (vec) SPICE_MM_LAUNCH_X3(true, 1);
-        else SPICE_MM_LAUNCH_X3(false, 1);
+        if (deep) SPICE_MM_LAUNCH_X3(3);
+        else SPICE_MM_LAUNCH_X3(1);
     } else if (p_mean != nullptr) {
-        if (deep && vec) SPICE_MM_LAUNCH_PRE(true, 3);
-        else if (deep) SPICE_MM_LAUNCH_PRE(false, 3);
-        else if (vec) SPICE_MM_LAUNCH_PRE(true, 1);
-        else SPICE_MM_LAUNCH_PRE(false, 1);
+        if (deep) SPICE_MM_LAUNCH_PRE(3);
+        else SPICE_MM_LAUNCH_PRE(1);
     } else if (s2) {
-        if (deep && vec) SPICE_MM_LAUNCH_S2(true, 3);
-        else if (deep) SPICE_MM_LAUNCH_S2(false, 3);
-        else if (vec) SPICE_MM_LAUNCH_S2(true, 1);
-        else SPICE_MM_LAUNCH_S2(false, 1);
+        if (deep) SPICE_MM_LAUNCH_S2(3);
+        else SPICE_MM_LAUNCH_S2(1);
     } else if (wide) {
-        if (vec) SPICE_MM_LAUNCH(true, 1, 2);
-        else SPICE_MM_LAUNCH(false, 1, 2);
+        SPICE_MM_LAUNCH(1, 2);
     } else if (deep) {
-        if (vec) SPICE_MM_LAUNCH(true, 3, 1);
-        else SPICE_MM_LAUNCH(false, 3, 1);
+        SPICE_MM_LAUNCH(3, 1);
     } else {
-        if (vec) SPICE_MM_LAUNCH(true, 1, 1);
-        else SPICE_MM_LAUNCH(false, 1, 1);
+        SPICE_MM_LAUNCH(1, 1);
     }
 #undef SPICE_MM_LAUNCH
 #undef SPICE_MM_LAUNCH_S2
 #undef SPICE_MM_LAUNCH_X3
 #undef SPICE_MM_LAUNCH_X3S2
 #undef SPICE_MM_LAUNCH_PRE
+#undef SPICE_MM_LAUNCH_ODD
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;
 }

@@ -132,6 +132,15 @@ def test_fused_rejects_what_it_cannot_take(dev):
         with pytest.raises(ValueError):
             ops.conv1x1_bn_act(x, wt, bn, None, None, True, route=5)
         assert ops.conv1x1_bn_act(x[:0], wt, bn, None, None, True).shape == (0, 4, 2, 3)
+    # through the C ABI: a weight matrix that does not start on 4 bytes (the base of a buffer descriptor) is refused
+    x = torch.randn(1, 8, 2, 4, device=dev).half()
+    flat = torch.randn(4 * 8 + 1, device=dev).half()
+    y = torch.zeros(1, 4, 2, 4, device=dev).half()
+    null = ctypes.c_void_p(0)
+    rc = nat.lib().spice_conv1x1_bn_act_f16(x.data_ptr(), flat.data_ptr() + 2, y.data_ptr(), 1, 8, 8, 4, null, null, null, null,
+                                            0.0, null, null, null, null, null, 0.0, 0, 0, null, null, null, null, 0.0, 0,
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == nat.ERR_UNSUPPORTED
 
 
 @pytest.mark.parametrize("route", [1, 2])

@@ -41,6 +41,7 @@ from spice_amd import nets, ops, synth  # noqa: E402
 from spice_amd.sweep import DEFAULT_RATIOS, SensitivitySweep  # noqa: E402
 
 PEAK_HBM_GBPS = 8000.0  # MI355X HBM3E peak
+PEAK_MFMA_F16_TFLOPS = 2500.0  # dense fp16 matrix-core peak
 CLASSES, BATCH, SIZE = 21, 8, 512
 
 
@@ -111,6 +112,12 @@ def kernel_table(dev):
         gbs = nbytes / ms / 1e6
         out.append({"kernel": name, "ms": round(ms, 4), "algorithmic_MB": round(nbytes / 1e6, 1),
                     "GBps": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBPS, 3)})
+
+    def row_flops(name, ms, macs, nbytes):
+        tf = 2 * macs / ms / 1e9
+        out.append({"kernel": name, "ms": round(ms, 4), "GFLOP": round(2 * macs / 1e9, 1), "TFLOPs": round(tf, 1),
+                    "frac_mfma": round(tf / PEAK_MFMA_F16_TFLOPS, 3), "algorithmic_MB": round(nbytes / 1e6, 1),
+                    "GBps": round(nbytes / ms / 1e6, 1)})
 
     shapes = synth.deeplab_resnet50_conv_shapes(CLASSES)
     offs, pos = [], 0
@@ -208,7 +215,57 @@ def kernel_table(dev):
         row("ResNet stem: batch-norm + ReLU + 3x3/2 max-pooling in one launch, [8,64,256,256] fp16",
             event_ms(lambda: ops.bn_act_maxpool(cyc(stem_in), norm64, want_full=False), 20),
             stem_in[0].numel() * 2 * 5 // 4)
+        # the same kernel where it is bound by the matrix cores and the tile traffic through L2 / LDS: deep K
+        for name, c, side, dil in (("3x3 convolution 512->512, dilation 2, + batch-norm + ReLU in one launch, [8,.,32,32] fp16", 512, 32, 2),
+                                   ("3x3 convolution 256->256 + batch-norm + ReLU in one launch, [8,.,32,32] fp16", 256, 32, 1)):
+            x3 = [torch.randn(BATCH, c, side, side, device=dev).half() for _ in range(4)]
+            w9 = (torch.randn(c, 9 * c, device=dev) / (9 * c) ** 0.5).half()
+            nrm = torch.nn.BatchNorm2d(c).eval().to(dev)
+            row_flops(name, event_ms(lambda: ops.conv3x3_bn_act(cyc(x3), w9, nrm, True, 1, dil), 20),
+                      BATCH * side * side * c * c * 9, 2 * x3[0].numel() * 2)
+        xa = [torch.randn(BATCH, 2048, 32, 32, device=dev).half() for _ in range(4)]
+        wa = (torch.randn(256, 2048, device=dev) / 2048 ** 0.5).half()
+        row_flops("1x1 convolution 2048->256 + batch-norm + ReLU in one launch, [8,.,32,32] fp16",
+                  event_ms(lambda: ops.conv1x1_bn_act(cyc(xa), wa, norm, None, None, True, route=1), 20),
+                  BATCH * 32 * 32 * 2048 * 256, 2 * (xa[0].numel() + BATCH * 256 * 32 * 32))
     return out
+
+
+def forward_probe(sweep, candidates, images, labels, teacher, table, kd):
+    """The matrix-core convolution kernel, which takes most of a step's device time, against the MFMA peak: a few
+    more candidates behind the timed region, with an event pair round every convolution call (not inside the timed
+    region: ~120 event records per step would be in its way)."""
+    records = []
+    ops.set_conv_probe(records)
+    try:
+        with sweep.session():
+            for c in candidates:
+                table[c].zero_()
+                sweep.evaluate(c, images, labels, teacher, table[c], kd[c])
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_probe(None)
+    mine = [r for r in records if r[0].startswith("matrix_core")]
+    ms = sum(a.elapsed_time(b) for _, a, b, _, _ in mine)
+    macs, nbytes = sum(r[3] for r in mine), sum(r[4] for r in mine)
+    steps = max(len(candidates), 1)
+    by_kind = {}
+    for kind, a, b, m, _ in mine:
+        d = by_kind.setdefault(kind, [0, 0.0, 0])
+        d[0] += 1
+        d[1] += a.elapsed_time(b)
+        d[2] += m
+    tflops = 2 * macs / ms / 1e9
+    return {"bound": "mfma", "kernel": "spice::conv1x1_bn_act_mfma_kernel (every instantiation: 1x1 pairs, stride-2 "
+            "shortcuts, 3x3 convolutions)", "achieved": round(tflops, 1), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tflops / PEAK_MFMA_F16_TFLOPS, 4), "launches_per_step": round(len(mine) / steps, 1),
+            "avg_launch_us": round(1e3 * ms / max(len(mine), 1), 2), "us_per_step": round(1e3 * ms / steps, 1),
+            "GFLOP_per_step": round(2 * macs / steps / 1e9, 1),
+            "algorithmic_GBps": round(nbytes / ms / 1e6, 1), "algorithmic_MB_per_step": round(nbytes / steps / 1e6, 1),
+            "by_kind": {k: {"launches_per_step": round(v[0] / steps, 1), "us_per_step": round(1e3 * v[1] / steps, 1),
+                            "TFLOPs": round(2 * v[2] / v[1] / 1e9, 1)} for k, v in by_kind.items()},
+            "measured": f"{steps} candidates behind the timed region, HIP events round each call on its stream "
+                        "(event pairs add gaps between launches, not to them)"}
 
 
 def cpu_candidate_baseline(model, sweep, images, labels):
@@ -442,8 +499,9 @@ def main():
                    "groups": len(sweep.groups), "ratios": list(DEFAULT_RATIOS),
                    "forward": "fp32" if args.fp32_forward else (
                        "fp16 autocast, every module on torch's kernels (A/B run)" if args.torch_forward else
-                       "fp16 autocast; 3x3 convolutions on MIOpen, 1x1 on hipBLASLt; up-sampling, batch-norm(+add+ReLU) and "
-                       "depthwise 3x3 on the library's kernels"),
+                       "fp16 autocast; 1x1 and 3x3 convolutions with their batch-norm (+ residual + ReLU) in one launch of the "
+                       "library's matrix-core kernel each, stem batch-norm + max-pooling, up-sampling and depthwise 3x3 on the "
+                       "library's kernels; the stem's 7x7 convolution on MIOpen, two long-K plain products on hipBLASLt"),
                    "kd": {"T": 4.0, "alpha": 0.7}, "parallelism": f"candidates sharded over {world} rank(s)"},
         "roofline": {"bound": "hbm", "kernel": "spice::kdlite_main_kernel<4,false,false,false> (one launch per "
                      "spice_kdlite_forward call)", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS,
@@ -456,6 +514,8 @@ def main():
                   "new_conv_problems_seen": n_warm, "taylor_calibration_s": round(taylor_s, 3), "taylor_batches": 2,
                   "quota_layers": len(quotas), "gather_MB_per_candidate": round(moved / max(args.steps, 1) / 1e6, 2)},
     }
+    if rank == 0 and not args.torch_forward and not args.fp32_forward:
+        result["forward_roofline"] = forward_probe(sweep, todo[args.warmup:args.warmup + 8], images, labels, teacher, table, kd)
     if not args.no_strong_block:
         # The strong-scaling figure beside the weak one: the whole sweep, all candidates shared by the ranks, on a
         # fresh SensitivitySweep (new launch plans).  It runs AFTER the timed region above, so the convolution

@@ -151,7 +151,7 @@ __device__ __forceinline__ uint4 mm_shift_halfs(uint4 v, int n) {
 }
 
 template <int STAGES, int MT, int XMODE = kXPlain, bool PRE = false, bool W_ODD = false>
-__global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, (STAGES > 1 || MT == 1) ? 4 : 2) void conv1x1_bn_act_mfma_kernel(MmArgs a) {
+__global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ? 4 : 2) void conv1x1_bn_act_mfma_kernel(MmArgs a) {
     constexpr int BM = kMmBM * MT;          // channels per workgroup: MT 32-channel product tiles per wave
     // deep K: eight waves, a 32-channel x 32-pixel product each (twice the waves to hide each other's waits: these
     // launches leave a compute unit one or two workgroups); otherwise four waves with 32 MT channels x 64 pixels each
@@ -161,7 +161,6 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, (STAGES >
     constexpr int B_PIECES = kMmBK * 8 / THREADS;         // ... of X
     constexpr int ROWS = BM * 8 / THREADS;                // rows per lane in the row-major pass of the epilogue
     constexpr int RSTEP = THREADS / 8;                    // ... which lie this many rows apart
-    static_assert(STAGES == 1 || MT == 1, "the eight-wave form has one 32-channel block per wave");
     constexpr bool DEEP = STAGES > 1;       // two LDS images: a step's products run beside the next step's stores
     constexpr int IMG = BM * kMmAPitch + kMmBK * kMmBPitch;   // halfs of one image (A tile, then X tile)
     __shared__ __attribute__((aligned(16))) _Float16 lds[(DEEP ? 2 : 1) * IMG];
@@ -580,11 +579,18 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     }
     const int64_t tiles_n = ceil_div(hw, kMmBN);
     // 256-channel tiles (two product tiles per wave: half the reads of X and of the LDS images per product) are an
-    // option (SPICE_CONV1X1_MT=2), not the default: at 206 registers a compute unit holds two workgroups instead of
-    // four, which on MI355X costs more than the traffic saves on every pair of the DeepLabV3+-ResNet-50 forward
+    // option (SPICE_CONV1X1_MT=2), not the default: at over 200 registers a compute unit holds two workgroups instead
+    // of four, which on MI355X costs more than the traffic saves on every pair of the DeepLabV3+-ResNet-50 forward
     // but one (tools/conv1x1_bench.py: 958 us per forward against 850 us)
-    const bool wide = mm_mt_knob() >= 2 && cout > kMmBM && x_h == 0 && p_mean == nullptr && !c3;
+    const bool wide = mm_mt_knob() >= 2 && cout > kMmBM && x_h == 0 && p_mean == nullptr && !c3 && (kdim & 1) == 0;
     const int64_t tiles_m = ceil_div(cout, wide ? 2 * kMmBM : kMmBM);
+    // deep K on a grid that leaves a compute unit one or two workgroups: the eight-wave form with two LDS images.
+    // (256-channel tiles in that form - one workgroup per compute unit where 128-channel tiles give two - move a
+    // sixth less through L2 and a quarter less through LDS and take the same time: 64.3 against 65.3 us for the
+    // 512-channel dilated 3x3 convolution; not kept.)
+    const long forced = mm_stages_knob();
+    const bool deep = !wide && (forced > 0 ? forced >= 3
+                                           : (kdim >= 4 * kMmBK && tiles_m * tiles_n * n <= 2 * static_cast<int64_t>(device_cu_count())));
     if (tiles_m * tiles_n > INT32_MAX / n) return SPICE_ERR_UNSUPPORTED;
     MmArgs a;
     a.x = static_cast<const _Float16 *>(x);
@@ -625,10 +631,6 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     a.relu = relu ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(a.total_tiles);
-    // deep K on a grid that leaves a compute unit one or two workgroups: the eight-wave form with two LDS images
-    const long forced = mm_stages_knob();
-    const bool deep = !wide && (forced > 0 ? forced >= 3
-                                           : (kdim >= 4 * kMmBK && static_cast<int64_t>(a.total_tiles) <= 2 * static_cast<int64_t>(device_cu_count())));
 #define SPICE_MM_LAUNCH(S, T) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<S, T>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
 #define SPICE_MM_LAUNCH_S2(S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<S, 1, kXStride2>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
 #define SPICE_MM_LAUNCH_X3(S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<S, 1, kX3x3>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)

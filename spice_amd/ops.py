@@ -474,6 +474,27 @@ def depthwise_conv3x3(x: torch.Tensor, weight: torch.Tensor, dilation: int = 1) 
 
 _conv1x1_fn = None
 
+# Measurement hook (bench.py): a list to which every convolution call below appends
+# (kind, start event, end event, multiply-adds, bytes of x + y [+ residual]); None = off, which costs one comparison.
+_conv_probe = None
+
+
+def set_conv_probe(records):
+    """records: a list to append to, or None to switch the hook off."""
+    global _conv_probe
+    _conv_probe = records
+
+
+def _probed(kind, fn, args, x, cout, k, residual=None):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    y = fn(*args)
+    e1.record()
+    pixels = y.numel() // cout
+    nbytes = 2 * (x.numel() + y.numel() + (residual.numel() if residual is not None else 0))
+    _conv_probe.append((kind, e0, e1, pixels * cout * k, nbytes))
+    return y
+
 
 def conv1x1_f16(x: torch.Tensor, weight2d: torch.Tensor, stride: int = 1) -> torch.Tensor:
     """weight2d[Cout, Cin] @ x[n][Cin, H*W] for fp16 NCHW x: a 1x1 convolution without bias.  Stride 1: the
@@ -483,6 +504,9 @@ def conv1x1_f16(x: torch.Tensor, weight2d: torch.Tensor, stride: int = 1) -> tor
     global _conv1x1_fn
     if _conv1x1_fn is None:
         _conv1x1_fn = spice_ops().conv1x1_f16
+    if _conv_probe is not None:
+        kind = "matrix_core_plain" if (stride == 2 or weight2d.shape[1] <= 256) else "hipblaslt_plain"
+        return _probed(kind, _conv1x1_fn, (x, weight2d, stride), x, weight2d.shape[0], weight2d.shape[1])
     return _conv1x1_fn(x, weight2d, stride)
 
 
@@ -507,8 +531,11 @@ def conv1x1_bn_act(x: torch.Tensor, weight2d: torch.Tensor, bn: "torch.nn.BatchN
                                                                res_bn.bias, res_bn.eps)
     p = (None, None, None, None, 0.0) if pre_bn is None else (pre_bn.running_mean, pre_bn.running_var, pre_bn.weight,
                                                               pre_bn.bias, pre_bn.eps)
-    return _conv1x1_bn_fn(x, weight2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, residual, *r, relu,
-                          route, out, *p, pre_relu)
+    args = (x, weight2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, residual, *r, relu, route, out, *p,
+            pre_relu)
+    if _conv_probe is not None:
+        return _probed("matrix_core_pair", _conv1x1_bn_fn, args, x, weight2d.shape[0], weight2d.shape[1], residual)
+    return _conv1x1_bn_fn(*args)
 
 
 def conv3x3_supported(x: torch.Tensor, stride: int, dilation: int) -> bool:
@@ -530,4 +557,7 @@ def conv3x3_bn_act(x: torch.Tensor, weight9: torch.Tensor, bn: "torch.nn.BatchNo
     global _conv3x3_fn
     if _conv3x3_fn is None:
         _conv3x3_fn = spice_ops().conv3x3_bn_act
-    return _conv3x3_fn(x, weight9, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, relu, stride, dilation)
+    args = (x, weight9, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, relu, stride, dilation)
+    if _conv_probe is not None:
+        return _probed("matrix_core_3x3", _conv3x3_fn, args, x, weight9.shape[0], weight9.shape[1])
+    return _conv3x3_fn(*args)

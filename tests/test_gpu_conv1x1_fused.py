@@ -40,7 +40,9 @@ SHAPES = [(2, 64, 16, 16, 256), (1, 40, 8, 24, 130), (3, 230, 4, 6, 77), (1, 8, 
           (3, 96, 8, 40, 300), (1, 33, 16, 8, 64), (8, 256, 32, 32, 48), (1, 328, 8, 8, 40), (2, 301, 4, 8, 140),
           (1, 640, 8, 16, 129),
           # many tiles and more than 128 channels; with an M tail, a K tail, unaligned rows
-          (8, 64, 64, 64, 300), (8, 72, 64, 64, 256), (8, 33, 64, 64, 257)]
+          (8, 64, 64, 64, 300), (8, 72, 64, 64, 256), (8, 33, 64, 64, 257),
+          # deep K on two 128-channel tiles per compute unit: the eight-wave form with 256-channel tiles, K tail
+          (8, 264, 32, 32, 512)]
 
 
 def _integer_case(shape, dev):

@@ -30,10 +30,9 @@ namespace spice {
 #define SPICE_FD1 1
 #endif
 constexpr int kMmThreads = 256;
-constexpr int kMmBM = 128, kMmBN = 64, kMmBK = 64;
+constexpr int kMmBM = 128, kMmBK = 64;   // channels per tile (x MT), K per step; pixels per tile: mm_tile_pixels
 constexpr int kMmAPitch = 72;    // halfs
 constexpr int kMmBPitch = 64;    // halfs (swizzled, no padding)
-constexpr int kMmCPitch = 72;    // halfs
 constexpr int kMmPreMaxK = 512;  // input channels whose pending batch-norm the kernel can hold in LDS (8 KB)
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
@@ -67,6 +66,12 @@ struct MmArgs {
 __device__ __forceinline__ unsigned mm_tile_of_block(unsigned id, unsigned total) {
     if (total % 8u != 0) return id;
     return (id & 7u) * (total >> 3) + (id >> 3);
+}
+
+// Pixels per tile of the forms: STAGES 1 (four waves) and 3 (eight waves) 64, STAGES 4 (eight waves) 128.
+constexpr int mm_tile_pixels(int stages) { return stages == 4 ? 128 : 64; }
+constexpr int mm_lds_bytes(int stages, int mt) {
+    return (stages > 1 ? 2 : 1) * (kMmBM * mt * kMmAPitch + kMmBK * mm_tile_pixels(stages)) * 2;
 }
 
 // Offset (halfs) of 16-byte piece `piece` (0..7) of row `k` of the B image.  Rows are 128 bytes, so rows k and
@@ -156,15 +161,18 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
     // deep K: eight waves, a 32-channel x 32-pixel product each (twice the waves to hide each other's waits: these
     // launches leave a compute unit one or two workgroups); otherwise four waves with 32 MT channels x 64 pixels each
     constexpr int THREADS = STAGES > 1 ? 2 * kMmThreads : kMmThreads;
-    constexpr int NT = STAGES > 1 ? 1 : 2;                // 32-pixel blocks per wave
+    constexpr int NPX = mm_tile_pixels(STAGES);   // pixels per tile: 64, or 128 as two 64-pixel sub-images side by side
+    constexpr int PCS = NPX / 8;                  // 16-byte pieces per row of the X tile and of the product
+    constexpr int NT = (STAGES > 1 && NPX == 64) ? 1 : 2;   // 32-pixel blocks per wave
     constexpr int A_PIECES = BM * 8 / THREADS;            // 16-byte pieces of A per lane and K step
-    constexpr int B_PIECES = kMmBK * 8 / THREADS;         // ... of X
-    constexpr int ROWS = BM * 8 / THREADS;                // rows per lane in the row-major pass of the epilogue
-    constexpr int RSTEP = THREADS / 8;                    // ... which lie this many rows apart
+    constexpr int B_PIECES = kMmBK * PCS / THREADS;       // ... of X
+    constexpr int ROWS = BM * PCS / THREADS;              // rows per lane in the row-major pass of the epilogue
+    constexpr int RSTEP = THREADS / PCS;                  // ... which lie this many rows apart
     constexpr bool DEEP = STAGES > 1;       // two LDS images: a step's products run beside the next step's stores
-    constexpr int IMG = BM * kMmAPitch + kMmBK * kMmBPitch;   // halfs of one image (A tile, then X tile)
-    __shared__ __attribute__((aligned(16))) _Float16 lds[(DEEP ? 2 : 1) * IMG];
-    static_assert(kMmCPitch <= kMmAPitch, "the C image fits in the A image's storage");
+    constexpr int IMG = BM * kMmAPitch + kMmBK * NPX;   // halfs of one image (A tile, then X tile)
+    constexpr int CP = NPX + 8;                   // pitch of the C image, halfs
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];   // (DEEP ? 2 : 1) * IMG halfs
+    static_assert(BM * CP <= (DEEP ? 2 : 1) * IMG, "the C image fits in the images' storage");
     __shared__ __attribute__((aligned(16))) float pre[PRE ? kMmPreMaxK * 4 : 4];   // (mean, inv, weight, bias) per input channel
     _Float16 *As = lds;
     _Float16 *Bs = lds + BM * kMmAPitch;
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
     const unsigned rest = tile / static_cast<unsigned>(a.tiles_m);
     const int nt = static_cast<int>(rest % static_cast<unsigned>(a.tiles_n));
     const size_t img = rest / static_cast<unsigned>(a.tiles_n);
-    const int m0 = mt * BM, n0 = nt * kMmBN;
+    const int m0 = mt * BM, n0 = nt * NPX;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
     }
 
     // the row-major pass of the epilogue: lane takes 8 consecutive pixels of one channel, ROWS such pieces
-    const int e_pc = (tid & 7) * 8, e_row = tid >> 3;   // rows e_row + RSTEP i
+    const int e_pc = (tid % PCS) * 8, e_row = tid / PCS;   // rows e_row + RSTEP i
     const int e_p = n0 + e_pc;
     const bool has_bn = a.mean != nullptr, has_res = a.res != nullptr, res_bn = a.r_mean != nullptr;
     uint4 rres[ROWS];
@@ -202,8 +210,9 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
         __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(a.w), 0, (a.M * a.K * 2 + 3) & ~3, 0x00020000);   // whole dwords: the range check is per dword
     const __amdgpu_buffer_rsrc_t x_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(xi), 0, x_chans * x_plane * 2, 0x00020000);
-    // the lane's piece of an X row: pixels n0 + 8 (tid & 7) .. +7 of the product (the same piece in every K step)
-    const int b_p = n0 + (tid & 7) * 8;
+    // the lane's piece of an X row: pixels n0 + 8 (tid % PCS) .. +7 of the product (the same piece in every K step)
+    const int b_pc = tid % PCS;
+    const int b_p = n0 + b_pc * 8;
     const bool b_in = b_p < a.hw;   // hw is a multiple of 8: a piece is inside the image or outside it
     int b_src = b_p;
     int b_yo = 0, b_xo = 0;   // the piece's row and first column in the product (a piece lies inside one row: y_w % 8 == 0)
@@ -222,13 +231,13 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
         const int m = m0 + (c >> 3);
         a_off[i] = m < a.M ? (m * a.K + (c & 7) * 8) * 2 : kMmOutside;
     }
-    // X, 1x1: channel (c >> 3) + 64 step; channels beyond K are beyond the buffer.
+    // X, 1x1: channel c / PCS + 64 step; channels beyond K are beyond the buffer.
     // X, 3x3: K row kk = tap * cin + ci is channel ci shifted by tap (dy, dx) * dilation; x3_chan = byte offset of the
     // channel, x3_dy / x3_dx = the shift, x3_tap > 8 = beyond K.
     int b_off[B_PIECES], x3_tap[B_PIECES], x3_ci[B_PIECES], x3_dy[B_PIECES], x3_dx[B_PIECES];
 #pragma unroll
     for (int i = 0; i < B_PIECES; ++i) {
-        const int kk = (tid + THREADS * i) >> 3;
+        const int kk = (tid + THREADS * i) / PCS;
         if constexpr (IS3) {
             x3_tap[i] = kk / a.cin;
             x3_ci[i] = kk - x3_tap[i] * a.cin;
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
                 if (rb_meta[i] != 0) piece = mm_shift_halfs(piece, rb_meta[i]);
             }
             if constexpr (PRE) {
-                const int kk = k0 + (c >> 3);
+                const int kk = k0 + c / PCS;
                 if (kk < a.K) {   // rows beyond K stay zero
                     const float4 q = *reinterpret_cast<const float4 *>(pre + 4 * kk);
                     const BnChannel ch = {q.x, q.y, q.z, q.w};
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
                     piece = __builtin_bit_cast(uint4, v);
                 }
             }
-            *reinterpret_cast<uint4 *>(Bs + image + mm_b_offset(c >> 3, c & 7)) = piece;
+            *reinterpret_cast<uint4 *>(Bs + image + (b_pc >> 3) * (kMmBK * kMmBPitch) + mm_b_offset(c / PCS, b_pc & 7)) = piece;
         }
     };
 
@@ -389,7 +398,8 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
     // operand addresses inside the LDS images (halfs), without the K-step part
     const int h = lane >> 5;
     const int wave_row = 32 * MT * (wave & 3);                            // first channel of the wave inside the tile
-    const int wave_px = NT == 1 ? wave >> 2 : 0;                          // first 32-pixel block of the wave
+    const int wave_px = NT == 1 ? wave >> 2 : 0;                          // first 32-pixel block of the wave ...
+    const int wave_sub = NPX == 128 ? wave >> 2 : 0;                      // ... inside this 64-pixel sub-image
     const int w_off = (wave_row + (lane & 31)) * kMmAPitch + 8 * h;       // + 32 mi rows + 16 s
     // transposed read: lane 4q + p of a 16-lane group supplies row q, pixels 4p .. 4p+3 of the group's 16 pixels
     const int g_b = (lane >> 4) & 1, g_q = (lane & 15) >> 2, g_p = lane & 3;
@@ -417,8 +427,8 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
                     // pixels 32 t + 16 g_b + 4 g_p ..: piece 4 t + 2 g_b + (g_p >> 1), second half of it for odd g_p
                     const int piece = 4 * (wave_px + t) + 2 * g_b + (g_p >> 1), within = 4 * (g_p & 1);
                     const int k_lo = 16 * s + x_row, k_hi = k_lo + 4;
-                    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(Bs + image + mm_b_offset(k_lo, piece) + within));
-                    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(Bs + image + mm_b_offset(k_hi, piece) + within));
+                    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(Bs + image + wave_sub * (kMmBK * kMmBPitch) + mm_b_offset(k_lo, piece) + within));
+                    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(Bs + image + wave_sub * (kMmBK * kMmBPitch) + mm_b_offset(k_hi, piece) + within));
                     const short8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     fx[sd][t] = __builtin_bit_cast(half8_t, both);
                 }
@@ -494,7 +504,7 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
                     half4_t v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = static_cast<_Float16>(acc[mi][t][4 * rq + e]);
-                    *reinterpret_cast<half4_t *>(Cs + row * kMmCPitch + 32 * (wave_px + t) + 8 * rq + 4 * h) = v;
+                    *reinterpret_cast<half4_t *>(Cs + row * CP + 64 * wave_sub + 32 * (wave_px + t) + 8 * rq + 4 * h) = v;
                 }
         }
     __syncthreads();
@@ -505,7 +515,7 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
         const int row = e_row + RSTEP * i;
         const int m = m0 + row;
         if (m >= a.M) break;   // rows ascend with i
-        half8_t v = *reinterpret_cast<const half8_t *>(Cs + row * kMmCPitch + e_pc);
+        half8_t v = *reinterpret_cast<const half8_t *>(Cs + row * CP + e_pc);
         if (has_bn) {
             const BnChannel pch = bn_channel_of(a.mean, a.var, a.weight, a.bias, a.eps, m);
             if (has_res) {
@@ -545,6 +555,18 @@ SPICE_ENV_KNOB(mm_mt_knob, "SPICE_CONV1X1_MT", 0)
 }  // namespace spice
 
 // x_h, x_w: the plane of x when the convolution has stride 2 (then hw = (x_h / 2) * (x_w / 2)), else 0
+// One launch of a form of the kernel: its LDS images as dynamic shared memory (the 128-pixel form's two images
+// take 68 KB, above what a kernel may have without asking).
+template <int STAGES, int MT, int XMODE = spice::kXPlain, bool PRE = false, bool W_ODD = false>
+static void mm_launch(const spice::MmArgs &a, hipStream_t st) {
+    using namespace spice;
+    constexpr int bytes = mm_lds_bytes(STAGES, MT);
+    const auto kernel = conv1x1_bn_act_mfma_kernel<STAGES, MT, XMODE, PRE, W_ODD>;
+    if constexpr (bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipLaunchKernelGGL(kernel, dim3(a.total_tiles), dim3(STAGES > 1 ? 2 * kMmThreads : kMmThreads), bytes, st, a);
+}
+
 static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int64_t hw,
                           int64_t cout, const float *mean, const float *var, const float *bn_weight,
                           const float *bn_bias, float eps, const void *residual, const float *r_mean,
@@ -577,20 +599,33 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
         const int64_t x_plane = x_h > 0 ? static_cast<int64_t>(x_h) * x_w : hw;
         if (cout * kdim * 2 > limit || cin * x_plane * 2 > limit) return SPICE_ERR_UNSUPPORTED;
     }
-    const int64_t tiles_n = ceil_div(hw, kMmBN);
     // 256-channel tiles (two product tiles per wave: half the reads of X and of the LDS images per product) are an
     // option (SPICE_CONV1X1_MT=2), not the default: at over 200 registers a compute unit holds two workgroups instead
     // of four, which on MI355X costs more than the traffic saves on every pair of the DeepLabV3+-ResNet-50 forward
     // but one (tools/conv1x1_bench.py: 958 us per forward against 850 us)
     const bool wide = mm_mt_knob() >= 2 && cout > kMmBM && x_h == 0 && p_mean == nullptr && !c3 && (kdim & 1) == 0;
     const int64_t tiles_m = ceil_div(cout, wide ? 2 * kMmBM : kMmBM);
-    // deep K on a grid that leaves a compute unit one or two workgroups: the eight-wave form with two LDS images.
-    // (256-channel tiles in that form - one workgroup per compute unit where 128-channel tiles give two - move a
-    // sixth less through L2 and a quarter less through LDS and take the same time: 64.3 against 65.3 us for the
-    // 512-channel dilated 3x3 convolution; not kept.)
+    // Which form: deep K on a grid that leaves a compute unit one or two workgroups -> eight waves, two LDS images
+    // (3); deep K on a grid with at least two 128-pixel tiles per compute unit -> the same with 128-pixel tiles,
+    // a third less traffic from L2 per product (4); else four waves, one image, four workgroups per compute unit (1).
+    // (256-channel tiles in the eight-wave form - one workgroup per compute unit where 128-channel tiles give two -
+    // take the same time: 64.3 against 65.3 us for the 512-channel dilated 3x3 convolution; not kept.)
     const long forced = mm_stages_knob();
-    const bool deep = !wide && (forced > 0 ? forced >= 3
-                                           : (kdim >= 4 * kMmBK && tiles_m * tiles_n * n <= 2 * static_cast<int64_t>(device_cu_count())));
+    const int64_t cus = device_cu_count();
+    const int64_t tiles64 = tiles_m * ceil_div(hw, 64) * n, tiles128 = tiles_m * ceil_div(hw, 128) * n;
+    const bool has_wide_pixels = p_mean == nullptr && !(x_h > 0 && !c3) && !(c3 && c3_stride == 2);   // forms with a 128-pixel variant
+    int form = 1;
+    if (!wide && (kdim & 1) == 0) {
+        if (forced > 0) form = forced >= 4 ? 4 : (forced >= 3 ? 3 : 1);
+        else if (kdim >= 4 * kMmBK && tiles64 <= 2 * cus)
+            // a plain or paired 1x1 product with K >= 512 gains from the wider tile as soon as every compute unit
+            // gets one (2048 -> 512 on 8,192 pixels: 25.8 against 28.5 us); the 3x3 mode does not (24.1 against 22.4)
+            form = (!c3 && kdim >= 8 * kMmBK && tiles128 >= cus && (hw & 127) == 0) ? 4 : 3;
+        else if (kdim >= 4 * kMmBK && tiles128 >= 2 * cus && (hw & 127) == 0) form = 4;
+    }
+    if (form == 4 && !has_wide_pixels) form = forced > 0 ? 3 : 1;
+    const bool deep = form >= 3;
+    const int64_t tiles_n = ceil_div(hw, form == 4 ? 128 : 64);
     if (tiles_m * tiles_n > INT32_MAX / n) return SPICE_ERR_UNSUPPORTED;
     MmArgs a;
     a.x = static_cast<const _Float16 *>(x);
@@ -630,44 +665,34 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     a.total_tiles = static_cast<unsigned>(tiles_m * tiles_n * n);
     a.relu = relu ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(a.total_tiles);
-#define SPICE_MM_LAUNCH(S, T) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<S, T>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
-#define SPICE_MM_LAUNCH_S2(S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<S, 1, kXStride2>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
-#define SPICE_MM_LAUNCH_X3(S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<S, 1, kX3x3>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
-#define SPICE_MM_LAUNCH_X3S2(S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<S, 1, kX3x3S2>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
-#define SPICE_MM_LAUNCH_ODD(X, P) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<1, 1, X, P, true>), grid, dim3(kMmThreads), 0, st, a)
-#define SPICE_MM_LAUNCH_PRE(S) hipLaunchKernelGGL((conv1x1_bn_act_mfma_kernel<S, 1, kXPlain, true>), grid, dim3((S) > 1 ? 2 * kMmThreads : kMmThreads), 0, st, a)
     if (kdim & 1) {   // pruned to an odd number of input channels: the forms that take rows of W from the middle of a dword
-        if (c3 && c3_stride == 2) SPICE_MM_LAUNCH_ODD(kX3x3S2, false);
-        else if (c3) SPICE_MM_LAUNCH_ODD(kX3x3, false);
-        else if (p_mean != nullptr) SPICE_MM_LAUNCH_ODD(kXPlain, true);
-        else if (s2) SPICE_MM_LAUNCH_ODD(kXStride2, false);
-        else SPICE_MM_LAUNCH_ODD(kXPlain, false);
+        if (c3 && c3_stride == 2) mm_launch<1, 1, kX3x3S2, false, true>(a, st);
+        else if (c3) mm_launch<1, 1, kX3x3, false, true>(a, st);
+        else if (p_mean != nullptr) mm_launch<1, 1, kXPlain, true, true>(a, st);
+        else if (s2) mm_launch<1, 1, kXStride2, false, true>(a, st);
+        else mm_launch<1, 1, kXPlain, false, true>(a, st);
     } else if (c3 && c3_stride == 2) {
-        if (deep) SPICE_MM_LAUNCH_X3S2(3);
-        else SPICE_MM_LAUNCH_X3S2(1);
+        if (deep) mm_launch<3, 1, kX3x3S2>(a, st);
+        else mm_launch<1, 1, kX3x3S2>(a, st);
     } else if (c3) {
-        if (deep) SPICE_MM_LAUNCH_X3(3);
-        else SPICE_MM_LAUNCH_X3(1);
+        if (form == 4) mm_launch<4, 1, kX3x3>(a, st);
+        else if (deep) mm_launch<3, 1, kX3x3>(a, st);
+        else mm_launch<1, 1, kX3x3>(a, st);
     } else if (p_mean != nullptr) {
-        if (deep) SPICE_MM_LAUNCH_PRE(3);
-        else SPICE_MM_LAUNCH_PRE(1);
+        if (deep) mm_launch<3, 1, kXPlain, true>(a, st);
+        else mm_launch<1, 1, kXPlain, true>(a, st);
     } else if (s2) {
-        if (deep) SPICE_MM_LAUNCH_S2(3);
-        else SPICE_MM_LAUNCH_S2(1);
+        if (deep) mm_launch<3, 1, kXStride2>(a, st);
+        else mm_launch<1, 1, kXStride2>(a, st);
     } else if (wide) {
-        SPICE_MM_LAUNCH(1, 2);
+        mm_launch<1, 2>(a, st);
+    } else if (form == 4) {
+        mm_launch<4, 1>(a, st);
     } else if (deep) {
-        SPICE_MM_LAUNCH(3, 1);
+        mm_launch<3, 1>(a, st);
     } else {
-        SPICE_MM_LAUNCH(1, 1);
+        mm_launch<1, 1>(a, st);
     }
-#undef SPICE_MM_LAUNCH
-#undef SPICE_MM_LAUNCH_S2
-#undef SPICE_MM_LAUNCH_X3
-#undef SPICE_MM_LAUNCH_X3S2
-#undef SPICE_MM_LAUNCH_PRE
-#undef SPICE_MM_LAUNCH_ODD
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;
 }

@@ -42,7 +42,9 @@ SHAPES = [(2, 64, 16, 16, 256), (1, 40, 8, 24, 130), (3, 230, 4, 6, 77), (1, 8, 
           # many tiles and more than 128 channels; with an M tail, a K tail, unaligned rows
           (8, 64, 64, 64, 300), (8, 72, 64, 64, 256), (8, 33, 64, 64, 257),
           # deep K on two 128-channel tiles per compute unit: the eight-wave form with 256-channel tiles, K tail
-          (8, 264, 32, 32, 512)]
+          (8, 264, 32, 32, 512),
+          # deep K on many tiles: the eight-wave form with 128-pixel tiles; M tail and K tail
+          (8, 264, 64, 64, 300), (8, 512, 32, 32, 512)]
 
 
 def _integer_case(shape, dev):

@@ -401,6 +401,15 @@ int spice_conv1x1_bn_act_f16(const void *x, const void *weight, void *y, int64_t
 int spice_conv1x1_stride2_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int32_t h,
                               int32_t w, int64_t cout, void *stream);
 
+/* A 7x7 convolution of stride 2 and padding 3 without bias (a ResNet stem) of fp16 NCHW activations, by the same
+ * matrix-core kernel: y[n][Cout, (h/2)*(w/2)] = weight[Cout, Cin*49] @ the 49 Cin shifted, column-halved views of x[n],
+ * which the kernel picks from x while it stages it (two 16-byte loads, the even or the odd halfs, zeros for the
+ * padding): no im2col buffer, no NHWC copies.  weight is [Cout][Cin][7][7] as torch keeps it.  h must be even, w a
+ * multiple of 16 and Cin <= 1024, else SPICE_ERR_UNSUPPORTED.  Replaces nothing in the reference itself: it is the
+ * convolution torch hands to MIOpen for `nn.Conv2d(3, 64, 7, 2, 3)` (smp's ResNet encoders). */
+int spice_conv7x7_stride2_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int32_t h,
+                              int32_t w, int64_t cout, void *stream);
+
 /* A 3x3 convolution (padding = dilation, no bias) of fp16 NCHW activations with the inference batch-norm (+ ReLU)
  * behind it, in one launch of the same matrix-core kernel: the nine taps are nine shifted 1x1 products in one sum
  * (conv2 + bn2 + relu of the bottlenecks of pruning/models.py:35-39's ResNet encoders, which torch serves with

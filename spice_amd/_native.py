@@ -104,6 +104,7 @@ SIGNATURES = {
     "spice_conv3x3_bn_act_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int64, c_int32,
                                            c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_void_p]),
     "spice_conv1x1_stride2_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int64, c_void_p]),
+    "spice_conv7x7_stride2_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int64, c_void_p]),
     "spice_conv1x1_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "spice_conv1x1_bn_act_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,

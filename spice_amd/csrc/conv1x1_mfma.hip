@@ -126,6 +126,7 @@ __device__ __forceinline__ half2_t bn_tail_pair(half2_t x, half2_t r, const BnCh
 // and below the image are zeros.
 constexpr int kMmOutside = 0x40000000;   // a byte offset outside W and outside an image of x (the host keeps both below 2^30 - 2^20), and still positive after a whole K of steps is added
 constexpr int kXPlain = 0, kXStride2 = 1, kX3x3 = 2, kX3x3S2 = 3;   // 3x3 with stride 1 / stride 2
+constexpr int kX7x7S2 = 4;   // 7x7, stride 2, padding 3 (a ResNet stem): K row kk is channel kk / 49, tap (kk % 49 / 7, kk % 7)
 typedef u32x4_t u32x4_any_t __attribute__((aligned(2)));   // a 16-byte load from a 2-byte aligned address
 
 // v's eight halfs moved up by n elements (n > 0: zeros enter at element 0) or down by -n (zeros enter at element 7)
@@ -200,8 +201,9 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
     uint4 rres[ROWS];
 
     constexpr bool IS3 = XMODE == kX3x3 || XMODE == kX3x3S2;
+    constexpr bool IS7 = XMODE == kX7x7S2;
     const int x_plane = XMODE != kXPlain ? a.x_hw : a.hw;   // pixels per channel of x
-    const int x_chans = IS3 ? a.cin : a.K;
+    const int x_chans = (IS3 || IS7) ? a.cin : a.K;
     const _Float16 *xi = a.x + img * static_cast<size_t>(x_chans) * x_plane;
     // W, and this image of x, behind buffer descriptors: 32-bit byte offsets, and an offset outside the buffer reads
     // zeros without touching memory - which is how rows beyond M, pixels beyond the image, channels beyond K and
@@ -245,6 +247,8 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
             x3_dy[i] = (ty - 1) * a.dil;
             x3_dx[i] = (x3_tap[i] - 3 * ty - 1) * a.dil;
             b_off[i] = x3_ci[i] * x_plane * 2;
+        } else if constexpr (IS7) {
+            b_off[i] = kk;   // the K row itself: the tap is decoded per step (three steps for three input channels)
         } else {
             b_off[i] = b_in ? (kk * x_plane + b_src) * 2 : kMmOutside;
         }
@@ -336,6 +340,25 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
                         x3_dx[i] += a.dil;
                     }
                 }
+            } else if constexpr (IS7) {
+                // output columns xo .. xo+7 of tap (ky, kx) read input columns 2 (xo + e) + kx - 3: the even or the odd
+                // halfs of the 16 columns from w0 on; at the row's ends the window is moved inside the row and the
+                // picked halfs shifted into place, zeros (the padding) coming in
+                const int kk = b_off[i];
+                const int c = kk / 49, r = kk - 49 * c, ky = r / 7, q = r - 7 * ky - 3;
+                const int iy = 2 * b_yo + ky - 3;
+                const bool in = b_in && kk < a.K && static_cast<unsigned>(iy) < static_cast<unsigned>(a.x_h);
+                const int w0 = 2 * b_xo + (q & ~1);
+                const int w0c = min(max(w0, 0), a.x_w - 16);
+                const int off = in ? (c * x_plane + iy * a.x_w + w0c) * 2 : kMmOutside;
+                const uint4 lo = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
+                const uint4 hi = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off + 16, 0, 0));
+                const uint4 picked = (q & 1) ? make_uint4((lo.x >> 16) | (lo.y & 0xffff0000u), (lo.z >> 16) | (lo.w & 0xffff0000u),
+                                                          (hi.x >> 16) | (hi.y & 0xffff0000u), (hi.z >> 16) | (hi.w & 0xffff0000u))
+                                             : make_uint4((lo.x & 0xffffu) | (lo.y << 16), (lo.z & 0xffffu) | (lo.w << 16),
+                                                          (hi.x & 0xffffu) | (hi.y << 16), (hi.z & 0xffffu) | (hi.w << 16));
+                rb[i] = w0c == w0 ? picked : mm_shift_halfs(picked, (w0c - w0) / 2);
+                b_off[i] += kMmBK;
             } else {
                 if constexpr (XMODE == kXStride2) {
                     const uint4 lo = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(x_rsrc, b_off[i], 0, 0));
@@ -567,6 +590,8 @@ static void mm_launch(const spice::MmArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(kernel, dim3(a.total_tiles), dim3(STAGES > 1 ? 2 * kMmThreads : kMmThreads), bytes, st, a);
 }
 
+constexpr int32_t kStem7x7 = -7;   // conv1x1_launch's c3_stride for the 7x7 stride-2 mode
+
 static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int64_t hw,
                           int64_t cout, const float *mean, const float *var, const float *bn_weight,
                           const float *bn_bias, float eps, const void *residual, const float *r_mean,
@@ -575,9 +600,10 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
                           const float *p_var, const float *p_weight, const float *p_bias, float p_eps, int32_t p_relu,
                           int32_t c3_stride, int32_t c3_dil, void *stream) {
     // c3_stride > 0: a 3x3 convolution of that stride and dilation c3_dil over x [n, cin, x_h, x_w]; weight is [cout][9][cin]
+    // c3_stride == kStem7x7: a 7x7 convolution, stride 2, padding 3; weight is [cout][cin][7][7] as it lies
     using namespace spice;
-    const bool c3 = c3_stride > 0;
-    const int64_t kdim = c3 ? 9 * cin : cin;   // length of the sums
+    const bool c3 = c3_stride > 0, c7 = c3_stride == kStem7x7;
+    const int64_t kdim = c7 ? 49 * cin : (c3 ? 9 * cin : cin);   // length of the sums
     if (n < 0 || cin <= 0 || hw < 0 || cout <= 0) return SPICE_ERR_ARG;
     if (n == 0 || hw == 0) return SPICE_OK;
     if (x == nullptr || weight == nullptr || y == nullptr) return SPICE_ERR_ARG;
@@ -615,7 +641,7 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     const int64_t tiles64 = tiles_m * ceil_div(hw, 64) * n, tiles128 = tiles_m * ceil_div(hw, 128) * n;
     const bool has_wide_pixels = p_mean == nullptr && !(x_h > 0 && !c3) && !(c3 && c3_stride == 2);   // forms with a 128-pixel variant
     int form = 1;
-    if (!wide && (kdim & 1) == 0) {
+    if (!wide && (kdim & 1) == 0 && !c7) {
         if (forced > 0) form = forced >= 4 ? 4 : (forced >= 3 ? 3 : 1);
         else if (kdim >= 4 * kMmBK && tiles64 <= 2 * cus)
             // a plain or paired 1x1 product with K >= 512 gains from the wider tile as soon as every compute unit
@@ -652,10 +678,10 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     a.M = static_cast<int>(cout);
     a.K = static_cast<int>(kdim);
     a.hw = static_cast<int>(hw);
-    const bool s2 = x_h > 0 && !c3;
+    const bool s2 = x_h > 0 && !c3 && !c7;
     a.x_hw = x_h > 0 ? x_h * x_w : 0;
     a.x_w = x_w;
-    a.y_w = s2 ? x_w / 2 : (c3 ? x_w / c3_stride : 0);
+    a.y_w = (s2 || c7) ? x_w / 2 : (c3 ? x_w / c3_stride : 0);
     a.x_h = x_h;
     a.cin = static_cast<int>(cin);
     a.stride = c3_stride;
@@ -665,7 +691,10 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     a.total_tiles = static_cast<unsigned>(tiles_m * tiles_n * n);
     a.relu = relu ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (kdim & 1) {   // pruned to an odd number of input channels: the forms that take rows of W from the middle of a dword
+    if (c7) {
+        if (kdim & 1) mm_launch<1, 1, kX7x7S2, false, true>(a, st);
+        else mm_launch<1, 1, kX7x7S2>(a, st);
+    } else if (kdim & 1) {   // pruned to an odd number of input channels: the forms that take rows of W from the middle of a dword
         if (c3 && c3_stride == 2) mm_launch<1, 1, kX3x3S2, false, true>(a, st);
         else if (c3) mm_launch<1, 1, kX3x3, false, true>(a, st);
         else if (p_mean != nullptr) mm_launch<1, 1, kXPlain, true, true>(a, st);
@@ -717,6 +746,17 @@ extern "C" int spice_conv1x1_stride2_f16(const void *x, const void *weight, void
     return conv1x1_launch(x, weight, y, n, cin, static_cast<int64_t>(h / 2) * (w / 2), cout, nullptr, nullptr, nullptr,
                           nullptr, 0.0f, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, 0, 0, h, w, nullptr, nullptr, nullptr,
                           nullptr, 0.0f, 0, 0, 0, stream);
+}
+
+extern "C" int spice_conv7x7_stride2_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int32_t h,
+                                         int32_t w, int64_t cout, void *stream) {
+    if (h <= 0 || w <= 0) return SPICE_ERR_ARG;
+    // whole 2x2 cells; rows of the product that are whole 16-byte pieces; a 16-column window inside a row
+    if ((h & 1) || (w & 15)) return SPICE_ERR_UNSUPPORTED;
+    if (cin > 1024) return SPICE_ERR_UNSUPPORTED;
+    return conv1x1_launch(x, weight, y, n, cin, static_cast<int64_t>(h / 2) * (w / 2), cout, nullptr, nullptr, nullptr,
+                          nullptr, 0.0f, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, 0, 0, h, w, nullptr, nullptr, nullptr,
+                          nullptr, 0.0f, 0, kStem7x7, 0, stream);
 }
 
 extern "C" int spice_conv3x3_bn_act_f16(const void *x, const void *weight9, void *y, int64_t n, int64_t cin, int32_t h,

@@ -569,6 +569,29 @@ Tensor conv1x1_bn_act(const Tensor &x, const Tensor &weight2d, const Tensor &mea
 
 // relu?( bn( conv2d(x, weight, stride, padding = dilation, dilation) ) ) for a 3x3 convolution; weight9 is the weight as
 // [Cout, 9 * Cin], tap-major.  One launch of the matrix-core kernel.
+// A 7x7 convolution of stride 2 and padding 3 without bias (the ResNet stem): weight as [Cout, Cin * 49], the
+// convolution's own weight tensor flattened.
+Tensor conv7x7_s2(const Tensor &x, const Tensor &weight2d) {
+    TORCH_CHECK_TYPE(x.scalar_type() == at::kHalf && weight2d.scalar_type() == at::kHalf,
+                     "conv7x7_s2: x and weight must be fp16");
+    TORCH_CHECK(x.is_cuda(), "x is on ", x.device(),
+                "; the MI355X path has no CPU implementation (move the tensor to a HIP device)");
+    TORCH_CHECK(weight2d.device() == x.device(), "conv7x7_s2: weight must be on x's device");
+    TORCH_CHECK_VALUE(x.dim() == 4 && weight2d.dim() == 2 && weight2d.size(1) == 49 * x.size(1) && x.is_contiguous() &&
+                          weight2d.is_contiguous(),
+                      "conv7x7_s2: x must be contiguous [N,Cin,H,W] and weight contiguous [Cout, Cin*49]");
+    const int64_t n = x.size(0), cin = x.size(1), h = x.size(2), w = x.size(3), cout = weight2d.size(0);
+    TORCH_CHECK_VALUE(h % 2 == 0 && w % 16 == 0 && h > 0 && w > 0,
+                      "conv7x7_s2: needs an even height and a width that is a multiple of 16");
+    c10::DeviceGuard guard(x.device());
+    Tensor out = at::empty({n, cout, h / 2, w / 2}, x.options());
+    if (out.numel() != 0)
+        check_rc(spice_conv7x7_stride2_f16(x.data_ptr(), weight2d.data_ptr(), out.data_ptr(), n, cin, (int32_t)h, (int32_t)w, cout,
+                                           current_stream(x)),
+                 "spice_conv7x7_stride2_f16");
+    return out;
+}
+
 Tensor conv3x3_bn_act(const Tensor &x, const Tensor &weight9, const Tensor &mean, const Tensor &var, const Tensor &weight,
                       const Tensor &bias, double eps, bool relu, int64_t stride, int64_t dilation) {
     TORCH_CHECK_TYPE(x.scalar_type() == at::kHalf && weight9.scalar_type() == at::kHalf,
@@ -628,6 +651,7 @@ TORCH_LIBRARY(spice, m) {
           "bool want_full) -> (Tensor, Tensor)", &bn_act_maxpool);
     m.def("depthwise_conv3x3(Tensor x, Tensor weight, int dilation) -> Tensor", &depthwise_conv3x3);
     m.def("conv1x1_f16(Tensor x, Tensor weight2d, int stride) -> Tensor", &conv1x1_f16);
+    m.def("conv7x7_s2(Tensor x, Tensor weight2d) -> Tensor", &conv7x7_s2);
     m.def("conv3x3_bn_act(Tensor x, Tensor weight9, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, "
           "bool relu, int stride, int dilation) -> Tensor", &conv3x3_bn_act);
     m.def("conv1x1_bn_act(Tensor x, Tensor weight2d, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, "

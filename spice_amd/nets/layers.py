@@ -90,7 +90,7 @@ class DepthwiseConv3x3(nn.Conv2d):
         return super().forward(x)
 
 
-# fp16 copies of convolution weights, per Parameter object: id -> (weak reference, version, [Cout, Cin] fp16).
+# fp16 copies of convolution weights, per Parameter object: id -> (weak reference, version, [Cout, Cin * kh * kw] fp16).
 # The same bookkeeping autocast does for the weights it casts: one cast per Parameter and version, dropped
 # with the Parameter.
 _FP16_WEIGHTS = {}
@@ -100,10 +100,36 @@ def _fp16_matrix(weight: torch.Tensor) -> torch.Tensor:
     key = id(weight)
     ent = _FP16_WEIGHTS.get(key)
     if ent is None or ent[0]() is not weight or ent[1] != weight._version:
-        w16 = weight.detach().to(torch.float16).view(weight.shape[0], weight.shape[1])
+        w16 = weight.detach().to(torch.float16).reshape(weight.shape[0], -1)
         ent = (weakref.ref(weight, lambda _, k=key: _FP16_WEIGHTS.pop(k, None)), weight._version, w16)
         _FP16_WEIGHTS[key] = ent
     return ent[2]
+
+
+class StemConv7x7(nn.Conv2d):
+    """nn.Conv2d(in_ch, out_ch, 7, stride=2, padding=3, bias=False): the ResNet stem.  On fp16 activations (autocast)
+    under no_grad on a HIP device, an even height and a width that is a multiple of 16, the forward is one launch of
+    the library's matrix-core kernel, which picks the 49 shifted, column-halved views of x itself (MIOpen serves this
+    convolution with an NHWC kernel between two layout transposes and a zero-fill).  Otherwise torch's conv2d."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__(in_channels, out_channels, 7, stride=2, padding=3, bias=False)
+
+    def served_by_library(self, x_dtype: torch.dtype, height: int, width: int) -> bool:
+        """Whether forward() on a plane of this size is a launch of the library (no MIOpen call, no solver lookup)."""
+        return (_LIBRARY_FORWARD and _LIBRARY_CONV7X7 and self.bias is None and self.groups == 1
+                and self.kernel_size == (7, 7) and self.stride == (2, 2) and self.padding == (3, 3)
+                and self.dilation == (1, 1) and self.padding_mode == "zeros" and height % 2 == 0 and width % 16 == 0
+                and self.in_channels <= 1024
+                and (x_dtype == torch.float16 or
+                     (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16)))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if (not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and not _hooked(self)
+                and self.served_by_library(x.dtype, x.shape[2], x.shape[3])):
+            x16 = x if x.dtype == torch.float16 else x.to(torch.float16)   # autocast's cast of a convolution's input
+            return ops.conv7x7_s2(x16.contiguous(), _fp16_matrix(self.weight))
+        return super().forward(x)
 
 
 class Conv1x1(nn.Conv2d):
@@ -225,6 +251,7 @@ def _fp16_taps(weight: torch.Tensor) -> torch.Tensor:
 
 
 # SPICE_CONV3X3=0 keeps the 3x3 convolutions with MIOpen (A/B measurements)
+_LIBRARY_CONV7X7 = os.environ.get("SPICE_CONV7X7", "1") != "0"
 _LIBRARY_CONV3X3 = os.environ.get("SPICE_CONV3X3", "1") != "0"
 
 

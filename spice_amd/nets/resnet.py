@@ -58,7 +58,7 @@ class ResNet50Encoder(nn.Module):
         super().__init__()
         if output_stride not in (16, 32):
             raise ValueError("output_stride must be 16 or 32")
-        self.conv1 = nn.Conv2d(in_channels, 64, 7, stride=2, padding=3, bias=False)
+        self.conv1 = layers.StemConv7x7(in_channels, 64)
         self.bn1 = BatchNormAct2d(64, relu=True)
         self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
         self.inplanes = 64

@@ -538,6 +538,20 @@ def conv1x1_bn_act(x: torch.Tensor, weight2d: torch.Tensor, bn: "torch.nn.BatchN
     return _conv1x1_bn_fn(*args)
 
 
+_conv7x7_fn = None
+
+
+def conv7x7_s2(x: torch.Tensor, weight2d: torch.Tensor) -> torch.Tensor:
+    """conv2d(x, W, stride=2, padding=3) for a 7x7 convolution without bias (the ResNet stem), fp16 NCHW, in one launch
+    of the matrix-core kernel.  weight2d: W flattened to [Cout, Cin * 49], fp16.  Height even, width a multiple of 16."""
+    global _conv7x7_fn
+    if _conv7x7_fn is None:
+        _conv7x7_fn = spice_ops().conv7x7_s2
+    if _conv_probe is not None:
+        return _probed("matrix_core_7x7", _conv7x7_fn, (x, weight2d), x, weight2d.shape[0], weight2d.shape[1])
+    return _conv7x7_fn(x, weight2d)
+
+
 def conv3x3_supported(x: torch.Tensor, stride: int, dilation: int) -> bool:
     """Whether conv3x3_bn_act takes this input: contiguous fp16 NCHW, the plane whole stride cells, rows of the result
     whole 16-byte pieces."""

@@ -30,7 +30,7 @@ from . import dist as sdist
 from . import ops
 from .engine import MagnitudeImportance, MagnitudePruner
 from .engine.pruner import SliceJob
-from .nets.layers import Conv1x1, conv3x3_served_by_library
+from .nets.layers import Conv1x1, StemConv7x7, conv3x3_served_by_library
 
 DEFAULT_RATIOS = (0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9)
 
@@ -215,7 +215,7 @@ class SensitivitySweep:
             key = (n, cin, h, w, cout, groups, mod.kernel_size, mod.stride, mod.padding, mod.dilation)
             if key in self._warmed or groups == cin:  # depthwise convolutions do not go through MIOpen
                 continue
-            if isinstance(mod, Conv1x1) and mod.served_by_library(self.autocast_dtype or in_dtype, h, w):
+            if isinstance(mod, (Conv1x1, StemConv7x7)) and mod.served_by_library(self.autocast_dtype or in_dtype, h, w):
                 continue  # a plain matrix product: no solver lookup to get out of the way
             if conv3x3_served_by_library(mod, self.autocast_dtype or in_dtype, h, w):
                 continue  # the library's own 3x3 kernel (the bottlenecks' convolutions): likewise

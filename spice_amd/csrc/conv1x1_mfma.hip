@@ -341,24 +341,7 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
                     }
                 }
             } else if constexpr (IS7) {
-                // output columns xo .. xo+7 of tap (ky, kx) read input columns 2 (xo + e) + kx - 3: the even or the odd
-                // halfs of the 16 columns from w0 on; at the row's ends the window is moved inside the row and the
-                // picked halfs shifted into place, zeros (the padding) coming in
-                const int kk = b_off[i];
-                const int c = kk / 49, r = kk - 49 * c, ky = r / 7, q = r - 7 * ky - 3;
-                const int iy = 2 * b_yo + ky - 3;
-                const bool in = b_in && kk < a.K && static_cast<unsigned>(iy) < static_cast<unsigned>(a.x_h);
-                const int w0 = 2 * b_xo + (q & ~1);
-                const int w0c = min(max(w0, 0), a.x_w - 16);
-                const int off = in ? (c * x_plane + iy * a.x_w + w0c) * 2 : kMmOutside;
-                const uint4 lo = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
-                const uint4 hi = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off + 16, 0, 0));
-                const uint4 picked = (q & 1) ? make_uint4((lo.x >> 16) | (lo.y & 0xffff0000u), (lo.z >> 16) | (lo.w & 0xffff0000u),
-                                                          (hi.x >> 16) | (hi.y & 0xffff0000u), (hi.z >> 16) | (hi.w & 0xffff0000u))
-                                             : make_uint4((lo.x & 0xffffu) | (lo.y << 16), (lo.z & 0xffffu) | (lo.w << 16),
-                                                          (hi.x & 0xffffu) | (hi.y << 16), (hi.z & 0xffffu) | (hi.w << 16));
-                rb[i] = w0c == w0 ? picked : mm_shift_halfs(picked, (w0c - w0) / 2);
-                b_off[i] += kMmBK;
+                // below, all pieces together
             } else {
                 if constexpr (XMODE == kXStride2) {
                     const uint4 lo = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(x_rsrc, b_off[i], 0, 0));
@@ -369,6 +352,37 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
                     rb[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(x_rsrc, b_off[i], 0, 0));
                 }
                 b_off[i] += kMmBK * x_plane * 2;
+            }
+        }
+        if constexpr (IS7) {
+            // output columns xo .. xo+7 of tap (ky, kx) read input columns 2 (xo + e) + kx - 3: the even or the odd
+            // halfs of the 16 columns from w0 on; at the row's ends the window is moved inside the row and the
+            // picked halfs shifted into place, zeros (the padding) coming in.  All loads first, then the picks.
+            uint4 lo[B_PIECES], hi[B_PIECES];
+            int odd[B_PIECES], shift[B_PIECES];
+#pragma unroll
+            for (int i = 0; i < B_PIECES; ++i) {
+                const int kk = b_off[i];
+                const int c = kk / 49, r = kk - 49 * c, ky = r / 7, q = r - 7 * ky - 3;
+                const int iy = 2 * b_yo + ky - 3;
+                const bool in = b_in && kk < a.K && static_cast<unsigned>(iy) < static_cast<unsigned>(a.x_h);
+                const int w0 = 2 * b_xo + (q & ~1);
+                const int w0c = min(max(w0, 0), a.x_w - 16);
+                const int off = in ? (c * x_plane + iy * a.x_w + w0c) * 2 : kMmOutside;
+                lo[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
+                hi[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off + 16, 0, 0));
+                odd[i] = q & 1;
+                shift[i] = (w0c - w0) / 2;
+                b_off[i] += kMmBK;
+            }
+#pragma unroll
+            for (int i = 0; i < B_PIECES; ++i) {
+                const uint4 l = lo[i], h = hi[i];
+                const uint4 picked = odd[i] ? make_uint4((l.x >> 16) | (l.y & 0xffff0000u), (l.z >> 16) | (l.w & 0xffff0000u),
+                                                         (h.x >> 16) | (h.y & 0xffff0000u), (h.z >> 16) | (h.w & 0xffff0000u))
+                                            : make_uint4((l.x & 0xffffu) | (l.y << 16), (l.z & 0xffffu) | (l.w << 16),
+                                                         (h.x & 0xffffu) | (h.y << 16), (h.z & 0xffffu) | (h.w << 16));
+                rb[i] = shift[i] == 0 ? picked : mm_shift_halfs(picked, shift[i]);
             }
         }
     };

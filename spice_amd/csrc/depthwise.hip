@@ -33,6 +33,30 @@ struct DwArgs {
     int w_is_f32;
 };
 
+// The nine taps of channel `ch` as raw bits (fp32 words or fp16 halfs): loads only, so that they are in flight together
+// with the loads of x; dw_taps_to_float turns them into the fp16 values (rounded from fp32 where the weights are fp32,
+// as autocast casts them) in fp32 registers.
+__device__ __forceinline__ void dw_load_taps(const DwArgs &a, int ch, unsigned (&raw)[9]) {
+    if (a.w_is_f32) {
+        const unsigned *wp = static_cast<const unsigned *>(a.w) + ch * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) raw[k] = wp[k];
+    } else {
+        const unsigned short *wp = static_cast<const unsigned short *>(a.w) + ch * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) raw[k] = wp[k];
+    }
+}
+
+__device__ __forceinline__ void dw_taps_to_float(const DwArgs &a, const unsigned (&raw)[9], float (&wt)[9]) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const _Float16 from_f32 = static_cast<_Float16>(__builtin_bit_cast(float, raw[k]));
+        const _Float16 from_f16 = __builtin_bit_cast(_Float16, static_cast<unsigned short>(raw[k]));
+        wt[k] = static_cast<float>(a.w_is_f32 ? from_f32 : from_f16);
+    }
+}
+
 __global__ __launch_bounds__(kDwThreads) void depthwise3x3_kernel(DwArgs a) {
     const int plane = blockIdx.x / a.blocks_per_plane;
     const int band = blockIdx.x - plane * a.blocks_per_plane;
@@ -44,13 +68,8 @@ __global__ __launch_bounds__(kDwThreads) void depthwise3x3_kernel(DwArgs a) {
     const int yc = min(y, a.h - 1);
     const int x0 = lx * 8;
 
-    float wt[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const _Float16 v = a.w_is_f32 ? static_cast<_Float16>(static_cast<const float *>(a.w)[ch * 9 + k])
-                                      : static_cast<const _Float16 *>(a.w)[ch * 9 + k];
-        wt[k] = static_cast<float>(v);
-    }
+    unsigned wraw[9];   // converted behind the loads of x: nothing waits for a tap before those are out
+    dw_load_taps(a, ch, wraw);
 
     const _Float16 *src = a.x + static_cast<int64_t>(plane) * a.h * a.wd;
     // all loads first, from clamped (always valid) addresses; what lies outside the plane is zeroed after
@@ -74,6 +93,8 @@ __global__ __launch_bounds__(kDwThreads) void depthwise3x3_kernel(DwArgs a) {
         for (int e = 0; e < 8; ++e) v[r][e + 1] = row_in ? static_cast<float>(mid[r][e]) : 0.0f;
         v[r][9] = row_in && x0 + 8 < a.wd ? static_cast<float>(right[r]) : 0.0f;
     }
+    float wt[9];
+    dw_taps_to_float(a, wraw, wt);
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
@@ -100,6 +121,7 @@ __global__ __launch_bounds__(kDwThreads) void depthwise3x3_kernel(DwArgs a) {
 // sum as it is).  A lane's 8 outputs read, per tap, two groups of four consecutive inputs; with the
 // dilation and the width multiples of 4 a group lies entirely inside or entirely outside the plane.
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 // A plane smaller than the workgroup (32x32: 128 lanes) shares it with the next plane(s): `planes_per_block`.
 __global__ __launch_bounds__(kDwThreads) void depthwise3x3_dilated_kernel(DwArgs a, int dil, int planes_per_block,
@@ -119,32 +141,41 @@ __global__ __launch_bounds__(kDwThreads) void depthwise3x3_dilated_kernel(DwArgs
     const int yc = min(y, a.h - 1);
     const int x0 = lx * 8;
 
-    float wt[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const _Float16 v = a.w_is_f32 ? static_cast<_Float16>(static_cast<const float *>(a.w)[ch * 9 + k])
-                                      : static_cast<const _Float16 *>(a.w)[ch * 9 + k];
-        wt[k] = static_cast<float>(v);
-    }
-    const _Float16 *src = a.x + static_cast<int64_t>(plane) * a.h * a.wd;
-    // a group outside the plane is not loaded (with a dilation beyond the plane size that is every tap but the centre)
+    unsigned wraw[9];   // converted behind the loads of x: nothing waits for a tap before those are out
+    dw_load_taps(a, ch, wraw);
+    // One 16-byte load per tap through a buffer descriptor over the plane (8-byte aligned: the dilation is a
+    // multiple of 4), nine loads with no branch between them - the address unit takes a wave's load in the same
+    // sixteen clocks whether a lane asks for 8 bytes or 16, and eighteen 8-byte loads per lane were what bounded this
+    // kernel.  A row above or below the plane is read from an offset outside the buffer (zeros, no memory access); a
+    // group of four to the right of the row comes back with the next row's values and is zeroed; a load that would
+    // start four columns left of the row starts at the row instead.
+    const int first = planes_per_block > 1 ? static_cast<int>(blockIdx.x) * planes_per_block
+                                           : static_cast<int>(blockIdx.x) / a.blocks_per_plane;   // uniform
+    const int here = max(min(planes_per_block, n_planes - first), 0);   // planes of this workgroup inside the tensor
+    const __amdgpu_buffer_rsrc_t plane_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16 *>(a.x + static_cast<int64_t>(min(first, n_planes - 1)) * a.h * a.wd), 0, here * a.h * a.wd * 2,
+        0x00020000);
+    const int plane_off = sub * a.h * a.wd;   // halfs, from the first plane of this workgroup
     f16x4_t g[3][3][2];
-    bool ok[3][3][2];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const int yy = yc + (r - 1) * dil;
         const bool row_in = active && yy >= 0 && yy < a.h;
-        const _Float16 *row = src + static_cast<int64_t>(min(max(yy, 0), a.h - 1)) * a.wd;
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int s = x0 + (j - 1) * dil + 4 * k;
-                ok[r][j][k] = row_in && s >= 0 && s + 4 <= a.wd;
-                g[r][j][k] = f16x4_t{0, 0, 0, 0};
-                if (ok[r][j][k]) g[r][j][k] = *reinterpret_cast<const f16x4_t *>(row + s);
-            }
+        for (int j = 0; j < 3; ++j) {
+            const int s = x0 + (j - 1) * dil;   // a multiple of 4: the groups s .. s+3 and s+4 .. s+7 are each inside the row or outside it
+            const bool neg = s < 0;             // then only s == -4 has a group inside: load from the row's start
+            const bool left = row_in && !neg && s + 4 <= a.wd, right = row_in && s + 4 >= 0 && s + 8 <= a.wd;
+            const int off = (left || right) ? (plane_off + yy * a.wd + (neg ? s + 4 : s)) * 2 : 0x40000000;
+            const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(plane_rsrc, off, 0, 0);
+            const unsigned r0 = left ? raw.x : 0u, r1 = left ? raw.y : 0u;
+            const unsigned r2 = right ? (neg ? raw.x : raw.z) : 0u, r3 = right ? (neg ? raw.y : raw.w) : 0u;
+            g[r][j][0] = __builtin_bit_cast(f16x4_t, uint2{r0, r1});
+            g[r][j][1] = __builtin_bit_cast(f16x4_t, uint2{r2, r3});
+        }
     }
+    float wt[9];
+    dw_taps_to_float(a, wraw, wt);
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
@@ -215,6 +246,8 @@ static int spice_depthwise_common(const void *x, const void *weight, int32_t wei
         const int lanes_per_plane = a.lanes_per_row * a.rows_per_block;
         const int ppb = a.blocks_per_plane == 1 ? kDwThreads / lanes_per_plane : 1;
         const int64_t grid = ppb > 1 ? ceil_div(n * c, ppb) : blocks;
+        // the kernel addresses the planes of a workgroup with 32-bit byte offsets
+        if (static_cast<int64_t>(h) * w * 2 * ppb >= (int64_t{1} << 30)) return SPICE_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(depthwise3x3_dilated_kernel, dim3(static_cast<unsigned>(grid)), dim3(kDwThreads), 0,
                            static_cast<hipStream_t>(stream), a, dilation, ppb, static_cast<int>(n * c));
     }

@@ -500,8 +500,9 @@ def main():
                    "forward": "fp32" if args.fp32_forward else (
                        "fp16 autocast, every module on torch's kernels (A/B run)" if args.torch_forward else
                        "fp16 autocast; 1x1 and 3x3 convolutions with their batch-norm (+ residual + ReLU) in one launch of the "
-                       "library's matrix-core kernel each, stem batch-norm + max-pooling, up-sampling and depthwise 3x3 on the "
-                       "library's kernels; the stem's 7x7 convolution on MIOpen, two long-K plain products on hipBLASLt"),
+                       "library's matrix-core kernel each, the stem's 7x7 convolution through the same kernel, stem batch-norm + "
+                       "max-pooling, up-sampling and depthwise 3x3 on the library's kernels; three plain 1x1 products on "
+                       "hipBLASLt; no MIOpen convolution"),
                    "kd": {"T": 4.0, "alpha": 0.7}, "parallelism": f"candidates sharded over {world} rank(s)"},
         "roofline": {"bound": "hbm", "kernel": "spice::kdlite_main_kernel<4,false,false,false> (one launch per "
                      "spice_kdlite_forward call)", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS,

@@ -228,11 +228,23 @@ class SensitivitySweep:
             warmed += 1
         return warmed
 
+    def _network_input(self, images: torch.Tensor) -> torch.Tensor:
+        """The batch as the first convolution reads it under autocast.  Every candidate sees the same batch, so the
+        cast is made once per batch tensor (address, version, shape), not once per candidate."""
+        if (self.autocast_dtype is None or not images.is_floating_point() or images.dtype == self.autocast_dtype
+                or not images.is_cuda):
+            return images
+        key = (images.data_ptr(), images._version, tuple(images.shape), images.dtype)
+        if getattr(self, "_cast_key", None) != key:
+            self._cast = images.to(self.autocast_dtype)
+            self._cast_key = key
+        return self._cast
+
     def forward(self, images: torch.Tensor) -> torch.Tensor:
         with torch.no_grad():
             if self.autocast_dtype is not None:
                 with torch.autocast("cuda", dtype=self.autocast_dtype):
-                    return self.model(images)
+                    return self.model(self._network_input(images))
             return self.model(images)
 
     def evaluate(self, index: int, images: torch.Tensor, labels: torch.Tensor,

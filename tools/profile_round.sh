@@ -27,4 +27,11 @@ timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_
 python3 tools/pmc_summary.py "$OUT/pmc_fetch_fwd" "$OUT/pmc_write_fwd" > "$OUT/pmc_traffic_forward_kernels.json"
 rm -rf "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_fetch_small "$OUT"/pmc_write_small "$OUT"/pmc_fetch_fwd "$OUT"/pmc_write_fwd
 find "$OUT" -name "*kernel_trace.csv" -size +20M -delete
+
+# 4. the convolution kernels against the libraries, shape by shape (HIP events, no profiler)
+timeout -k 10 300 python3 tools/conv1x1_bench.py --plain > "$OUT/conv1x1_pairs_fused_vs_two_launches.jsonl" 2>/dev/null
+timeout -k 10 300 python3 tools/conv3x3_bench.py > "$OUT/conv3x3_library_vs_miopen.jsonl" 2>/dev/null
+timeout -k 10 100 python3 tools/conv7x7_bench.py >> "$OUT/conv3x3_library_vs_miopen.jsonl" 2>/dev/null
+timeout -k 10 300 python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
+echo convolution benches done
 echo profile pass done

@@ -383,6 +383,8 @@ def main():
     ap.add_argument("--no-strong-block", action="store_true",
                     help="skip the whole-sweep (strong scaling) measurement that follows the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="candidates evaluated at a time per rank: copies of the network on streams of their own (1 = one after the other)")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--fp32-forward", action="store_true", help="forward without fp16 autocast")
     ap.add_argument("--warm-mode", default="upfront", choices=["upfront", "none"],
@@ -430,6 +432,7 @@ def main():
     sweep = SensitivitySweep(model, CLASSES, DEFAULT_RATIOS, ignored_layers=ignored,
                              autocast_dtype=None if args.fp32_forward else torch.float16)
     n_cand = len(sweep.candidates)
+    lanes = sweep.enable_lanes(args.lanes)
     if args.strong:
         # per-process library initialisation, like the find-database warm-up: the first forward of the un-pruned
         # network at this geometry (MIOpen's first call per convolution problem, hipBLASLt plans, autocast copies)
@@ -453,9 +456,12 @@ def main():
         table = torch.zeros(n_cand, CLASSES, CLASSES, dtype=torch.int64, device=dev)
         kd = torch.zeros(n_cand, 3, dtype=torch.float32, device=dev)
 
+        sweep.fork_lanes()
         for i in range(args.warmup):
-            table[todo[i]].zero_()
+            with sweep.lane_context(todo[i]):
+                table[todo[i]].zero_()
             sweep.evaluate(todo[i], images, labels, teacher, table[todo[i]], kd[todo[i]])
+        sweep.join_lanes()
         sweep.kd_events = []
         sdist.barrier()
         torch.cuda.synchronize()
@@ -468,8 +474,10 @@ def main():
         prep_s = time.perf_counter() - t0
         moved = 0
         for i in range(args.warmup, total_steps):
-            table[todo[i]].zero_()
+            with sweep.lane_context(todo[i]):
+                table[todo[i]].zero_()
             moved += sweep.evaluate(todo[i], images, labels, teacher, table[todo[i]], kd[todo[i]])
+        sweep.join_lanes()
         sdist.all_reduce_sum_(table)
         sdist.all_reduce_sum_(kd)
         torch.cuda.synchronize()
@@ -478,11 +486,24 @@ def main():
     n_warm = len(sweep._warmed)
     kd_events = sweep.kd_events
     sweep.kd_events = None
+    kd_events_alone = kd_events
+    if lanes > 1:
+        # With several candidates in flight the loss kernel shares the device with the other lane's convolutions and
+        # its duration says how they split the memory system, not how good the kernel is: the same K candidates once
+        # more, one at a time on the current stream, for the duration of the kernel by itself.
+        sweep.kd_events = []
+        with sweep.session():
+            for i in range(args.warmup, total_steps):
+                table[todo[i]].zero_()
+                sweep.evaluate(todo[i], images, labels, teacher, table[todo[i]], kd[todo[i]], first_lane=True)
+        torch.cuda.synchronize()
+        kd_events_alone, sweep.kd_events = sweep.kd_events, None
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     sdist.all_reduce_max_(t)
     elapsed = float(t.item())
 
-    kd_ms = float(np.mean([a.elapsed_time(b) for a, b in kd_events])) if kd_events else float("nan")
+    kd_ms_shared = float(np.mean([a.elapsed_time(b) for a, b in kd_events])) if kd_events else float("nan")
+    kd_ms = float(np.mean([a.elapsed_time(b) for a, b in kd_events_alone])) if kd_events_alone else float("nan")
     kd_bytes = BATCH * SIZE * SIZE * (2 * CLASSES * 4 + 8)
     achieved = kd_bytes / kd_ms / 1e6
     result = {
@@ -503,20 +524,33 @@ def main():
                        "library's matrix-core kernel each, the stem's 7x7 convolution through the same kernel, stem batch-norm + "
                        "max-pooling, up-sampling and depthwise 3x3 on the library's kernels; three plain 1x1 products on "
                        "hipBLASLt; no MIOpen convolution"),
-                   "kd": {"T": 4.0, "alpha": 0.7}, "parallelism": f"candidates sharded over {world} rank(s)"},
+                   "kd": {"T": 4.0, "alpha": 0.7},
+                   "parallelism": f"candidates sharded over {world} rank(s); {lanes} candidate(s) in flight per rank "
+                                  "(copies of the network on streams of their own, one host thread)"},
         "roofline": {"bound": "hbm", "kernel": "spice::kdlite_main_kernel<4,false,false,false> (one launch per "
                      "spice_kdlite_forward call)", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS,
                      "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4),
                      "traffic": pmc_traffic("spice::kdlite_main_kernel<4, false, false, false>")[0],
                      "traffic_source": pmc_traffic("spice::kdlite_main_kernel<4, false, false, false>")[1],
                      "algorithmic_bytes_per_launch": kd_bytes, "avg_launch_us": round(1e3 * kd_ms, 2),
-                     "launches_timed": len(kd_events)},
+                     "launches_timed": len(kd_events_alone),
+                     "measured": ("HIP events round the K launches of the timed region" if lanes == 1 else
+                                  "HIP events round the launches of the same K candidates evaluated once more behind the "
+                                  "timed region, one candidate on the device at a time (as `--lanes 1` times them "
+                                  "inside it)"),
+                     "in_timed_region": {"avg_launch_us": round(1e3 * kd_ms_shared, 2),
+                                         "frac": round(kd_bytes / kd_ms_shared / 1e6 / PEAK_HBM_GBPS, 4),
+                                         "candidates_in_flight": lanes,
+                                         "note": "the kernel's launches overlap the other lane's convolutions and share "
+                                                 "the memory system with them"}},
         "setup": {"miopen_find_db_warmup_s": round(tune_s, 1), "timed_prepare_s": round(prep_s, 4), "warm_mode": args.warm_mode,
                   "new_conv_problems_seen": n_warm, "taylor_calibration_s": round(taylor_s, 3), "taylor_batches": 2,
                   "quota_layers": len(quotas), "gather_MB_per_candidate": round(moved / max(args.steps, 1) / 1e6, 2)},
     }
     if rank == 0 and not args.torch_forward and not args.fp32_forward:
-        result["forward_roofline"] = forward_probe(sweep, todo[args.warmup:args.warmup + 8], images, labels, teacher, table, kd)
+        # candidates of the first lane: one after the other on the current stream
+        probe = [c for c in dict.fromkeys(todo[args.warmup:]) if c % lanes == 0][:8]
+        result["forward_roofline"] = forward_probe(sweep, probe, images, labels, teacher, table, kd)
     if not args.no_strong_block:
         # The strong-scaling figure beside the weak one: the whole sweep, all candidates shared by the ranks, on a
         # fresh SensitivitySweep (new launch plans).  It runs AFTER the timed region above, so the convolution
@@ -524,6 +558,7 @@ def main():
         # cost tens of microseconds instead of ~0.4 ms each (at most 70 candidates' worth per rank).
         fresh = SensitivitySweep(model, CLASSES, DEFAULT_RATIOS, ignored_layers=ignored,
                                  autocast_dtype=None if args.fp32_forward else torch.float16)
+        fresh.enable_lanes(args.lanes)
         w = whole_sweep(fresh, images, labels, dev, rank, world)
         w["scaling"] = "strong"
         w["workload"] = STRONG_WORKLOAD

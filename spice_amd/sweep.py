@@ -18,6 +18,7 @@ is combined with one all-reduce.
 from __future__ import annotations
 
 import contextlib
+import copy
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -50,6 +51,11 @@ class SensitivitySweep:
                  autocast_dtype: Optional[torch.dtype] = torch.float16,
                  kd_temperature: float = 4.0, kd_alpha: float = 0.7):
         self.model = model.eval()
+        self._ctor = dict(num_classes=num_classes, ratios=tuple(ratios), importance=importance,
+                          ignored_layers=list(ignored_layers) if ignored_layers is not None else None,
+                          autocast_dtype=autocast_dtype, kd_temperature=kd_temperature, kd_alpha=kd_alpha)
+        self._lanes: List["SensitivitySweep"] = [self]
+        self._stream: Optional[torch.cuda.Stream] = None   # lanes beyond the first: their own stream
         self.num_classes = num_classes
         self.autocast_dtype = autocast_dtype
         self.kd = dict(temperature=kd_temperature, alpha=kd_alpha)
@@ -160,7 +166,74 @@ class SensitivitySweep:
         self._geometry_for = shape
 
     # -- host preparation for a set of candidates: plans + one shared index upload
+    # -- lanes: further copies of the network, each with its own launch plans and its own stream -------------
+    def enable_lanes(self, count: int) -> int:
+        """Evaluate `count` candidates at a time: candidate i belongs to lane i % count, a copy of the network
+        with launch plans of its own, whose launches go to a stream of its own.  One host thread feeds all of
+        them; on the device the lanes' kernels fill each other's ramps, tails and half-empty launches (two
+        processes sharing an MI355X evaluate 16 % more candidates per second than one; this is the same overlap
+        without the second process).  Results are those of one lane: every candidate still runs the same kernels
+        on the same values.  Returns the number of lanes in use (1 on a device without streams)."""
+        count = max(int(count), 1)
+        if self.device.type != "cuda" or count == 1:
+            self._lanes = [self]
+            return 1
+        imp = self._ctor["importance"]
+        names = {m: n for n, m in self.model.named_modules()}
+        while len(self._lanes) < count:
+            replica = copy.deepcopy(self.model)
+            by_name = dict(replica.named_modules())
+            ignored = self._ctor["ignored_layers"]
+            lane = SensitivitySweep(replica, self._ctor["num_classes"], self._ctor["ratios"],
+                                    importance=None if imp is None else copy.deepcopy(imp),
+                                    ignored_layers=None if ignored is None else [by_name[names[m]] for m in ignored],
+                                    autocast_dtype=self._ctor["autocast_dtype"],
+                                    kd_temperature=self._ctor["kd_temperature"], kd_alpha=self._ctor["kd_alpha"])
+            same = len(lane.candidates) == len(self.candidates) and all(
+                a.group == b.group and np.array_equal(a.pruned, b.pruned) for a, b in zip(lane.candidates, self.candidates))
+            if not same:
+                raise RuntimeError("a copy of the network does not give the same candidates")
+            lane._twin_of = {by_name[n]: m for m, n in names.items()}   # its modules -> this network's
+            lane._stream = torch.cuda.Stream(device=self.device)
+            lane._stream.wait_stream(torch.cuda.current_stream(self.device))
+            self._lanes.append(lane)
+        del self._lanes[count:]
+        return len(self._lanes)
+
+    def _lane_of(self, index: int) -> "SensitivitySweep":
+        return self._lanes[index % len(self._lanes)]
+
+    @contextlib.contextmanager
+    def lane_context(self, index: int):
+        """The stream candidate `index` is evaluated on, as the current stream (for what the caller launches around
+        evaluate() on the candidate's own outputs, such as clearing its confusion matrix)."""
+        lane = self._lane_of(index)
+        if lane._stream is None:
+            yield
+        else:
+            with torch.cuda.stream(lane._stream):
+                yield
+
+    def fork_lanes(self) -> None:
+        """Everything queued on the current stream so far (inputs, teacher logits, cleared outputs) comes before what
+        the other lanes launch from here on."""
+        for lane in self._lanes[1:]:
+            lane._stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def join_lanes(self) -> None:
+        """What the other lanes have launched so far comes before what the current stream launches from here on."""
+        for lane in self._lanes[1:]:
+            torch.cuda.current_stream(self.device).wait_stream(lane._stream)
+
     def prepare(self, indices: Sequence[int]) -> None:
+        if len(self._lanes) > 1:
+            n = len(self._lanes)
+            for k, lane in enumerate(self._lanes):
+                lane._prepare([i for i in indices if i % n == k])
+        else:
+            self._prepare(indices)
+
+    def _prepare(self, indices: Sequence[int]) -> None:
         todo = [i for i in indices if i not in self.jobs]
         jobs = [SliceJob([(self.groups[self.candidates[i].group], self.candidates[i].pruned)]) for i in todo]
         arrays, starts, pos = [], [], 0
@@ -195,6 +268,18 @@ class SensitivitySweep:
         Doing the lookups on a helper thread instead does not pay: they wait for the device queue the
         evaluation loop keeps full, and the loop ends up waiting for the helper.  Returns the number
         of problems warmed."""
+        if len(self._lanes) > 1:   # each lane for its own candidates (its plans name its own copy's modules)
+            n = len(self._lanes)
+            self._ensure_geometry(images)
+            for lane in self._lanes[1:]:   # the copies see the same geometry: no forward of their own to learn it
+                lane._geometry = {m: self._geometry[t] for m, t in lane._twin_of.items() if t in self._geometry}
+                lane._geometry_for = self._geometry_for
+            return sum(lane._warm_shapes(images, [i for i in indices if i % n == k]) for k, lane in enumerate(self._lanes))
+        return self._warm_shapes(images, indices)
+
+    def _warm_shapes(self, images: torch.Tensor, indices: Sequence[int]) -> int:
+        if not indices:
+            return 0
         self._ensure_geometry(images)
         warmed = 0
         for i in indices:
@@ -249,11 +334,20 @@ class SensitivitySweep:
 
     def evaluate(self, index: int, images: torch.Tensor, labels: torch.Tensor,
                  teacher_logits: Optional[torch.Tensor], conf_out: torch.Tensor,
-                 kd_out: Optional[torch.Tensor] = None) -> int:
+                 kd_out: Optional[torch.Tensor] = None, first_lane: bool = False) -> int:
         """Enqueue one candidate; conf_out [C,C] int64 (+=), kd_out [3] fp32 (=).  Returns the
-        algorithmic bytes of the gather launch."""
+        algorithmic bytes of the gather launch.  first_lane: on this network and the current stream whatever lane
+        the candidate belongs to (measurements that want one candidate on the device at a time)."""
+        lane = self if first_lane else self._lane_of(index)
+        if lane is not self:
+            with torch.cuda.stream(lane._stream):
+                return lane._evaluate(index, images, labels, teacher_logits, conf_out, kd_out, self.kd_events)
+        return self._evaluate(index, images, labels, teacher_logits, conf_out, kd_out, self.kd_events)
+
+    def _evaluate(self, index: int, images: torch.Tensor, labels: torch.Tensor, teacher_logits: Optional[torch.Tensor],
+                  conf_out: torch.Tensor, kd_out: Optional[torch.Tensor], kd_events: Optional[list]) -> int:
         if index not in self.jobs:
-            self.prepare([index])
+            self._prepare([index])
         job = self.jobs[index]
         moved = job.run(keep_undo=True)
         try:
@@ -261,13 +355,13 @@ class SensitivitySweep:
             ops.argmax_confusion_update(conf_out, logits, labels, self.num_classes)
             if teacher_logits is not None and kd_out is not None:
                 student = logits.float()
-                if self.kd_events is not None:
+                if kd_events is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                 out3, _, _ = ops.kdlite_forward(student, teacher_logits, labels, **self.kd)
-                if self.kd_events is not None:
+                if kd_events is not None:
                     e1.record()
-                    self.kd_events.append((e0, e1))
+                    kd_events.append((e0, e1))
                 kd_out.copy_(out3)
         finally:
             job.undo()
@@ -312,8 +406,10 @@ class SensitivitySweep:
                 teacher = (unpruned_logits if unpruned_logits is not None else self.forward(images)).float().contiguous()
             dev_sync()
             ph["teacher_forward_s"], t = time.perf_counter() - t, time.perf_counter()
+            self.fork_lanes()
             for i in mine:   # no communication before the final all-reduce
                 self.evaluate(i, images, labels, teacher, table[i], kd[i] if with_kd else None)
+            self.join_lanes()
             dev_sync()   # this rank's own work, for the busy / idle split
             ph["candidates_s"] = time.perf_counter() - t
             self.last_share["busy_s"] = time.perf_counter() - t0

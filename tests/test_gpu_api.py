@@ -230,6 +230,32 @@ def test_sweep_candidate_equals_separately_pruned_model(dev):
     assert torch.isfinite(res["kd"][pick]).all() and (res["kd"][pick][:, 2] >= -1e-6).all()  # KL of nearly equal logits: fp32 noise around 0
 
 
+def test_sweep_lanes_give_the_results_of_one_lane(dev):
+    """Two and three candidates in flight (copies of the network on streams of their own) against one: the same
+    confusion matrices bit for bit (fp16 autocast forward: every convolution on the library's kernels, which give the
+    same values on every call), the same losses to 1e-5, and the network itself untouched."""
+    torch.manual_seed(11)
+    model = nets.create_model("DeepLabV3Plus", "resnet50", 7).to(dev).eval()
+    ignored = [m for m in model.segmentation_head.modules() if isinstance(m, nn.Conv2d)]
+    before = copy.deepcopy(model.state_dict())
+    x = torch.randn(2, 3, 128, 128, device=dev)
+    lab = torch.from_numpy(synth.label_map(2, 2, 128, 128, 7, "blocky")).to(dev)
+    pick = sorted(set(range(0, 92, 7)) | {1, 2, 90, 91})
+    results = []
+    for lanes in (1, 2, 3):
+        sweep = SensitivitySweep(model, 7, ratios=(0.25, 0.5), ignored_layers=ignored)
+        assert sweep.enable_lanes(lanes) == lanes
+        results.append(sweep.run(x, lab, indices=pick))
+        for k, v in model.state_dict().items():
+            assert torch.equal(v, before[k]), k
+    for res in results[1:]:
+        assert torch.equal(res["confusion"], results[0]["confusion"])
+        # the loss kernel sums its workgroups' partial sums in the order they finish: 1e-5 relative, and 1e-7 absolute
+        # for the KL term, which is ~1e-6 here (the un-pruned network is the teacher)
+        assert torch.allclose(res["kd"], results[0]["kd"], rtol=1e-5, atol=1e-7)
+    assert int(results[0]["confusion"][pick].sum()) == len(pick) * int((lab != 255).sum())
+
+
 def test_prune_model_end_to_end(dev, tmp_path):
     cfg = PruningConfig(model_name="DeepLabV3Plus_resnet", output_dir=str(tmp_path), data_root=str(tmp_path / "nodata"),
                         num_classes=5, input_size=(64, 64), example_input_size=(1, 3, 64, 64),

@@ -9,6 +9,9 @@ cp "$S/bench_line.json" "$D/bench_n1_under_rocprof.json"
 cp "$S/bench/bench_kernel_stats.csv" "$D/bench_kernel_stats.csv"
 cp "$S/bench_medians.txt" "$D/bench_kernel_medians.txt"
 cp "$S/sweep_step_breakdown.txt" "$D/"
+cp "$S/bench_lanes1_line.json" "$D/bench_n1_lanes1_under_rocprof.json"
+cp "$S/bench_lanes1/bench_kernel_stats.csv" "$D/bench_lanes1_kernel_stats.csv"
+cp "$S/bench_lanes1_medians.txt" "$D/bench_lanes1_kernel_medians.txt"
 cp "$S/kbench/kb_kernel_stats.csv" "$D/kbench_kernel_stats.csv"
 cp "$S/kbench_medians.txt" "$D/kbench_kernel_medians.txt"
 cp "$S/kbench_fwd/kb_kernel_stats.csv" "$D/kbench_forward_kernel_stats.csv"

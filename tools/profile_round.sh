@@ -11,10 +11,13 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 python3 tools/trace_medians.py "$OUT/kbench" > "$OUT/kbench_medians.txt"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kbench_fwd" -o kb -- python3 tools/kbench.py --only upsample,depthwise,bnact,conv1x1,stem --iters 25 > "$OUT/kbench_fwd.log" 2>&1
 python3 tools/trace_medians.py "$OUT/kbench_fwd" > "$OUT/kbench_fwd_medians.txt"
-# 2. the bench command itself
+# 2. the bench command itself (two candidates in flight: kernels of the two lanes overlap on the device) ...
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o bench -- python3 bench.py --no-cpu-baseline > "$OUT/bench_line.json" 2> "$OUT/bench.err"
 python3 tools/trace_medians.py "$OUT/bench" > "$OUT/bench_medians.txt"
-python3 tools/stepbreakdown.py "$(find "$OUT/bench" -name "*kernel_trace.csv" | head -1)" > "$OUT/sweep_step_breakdown.txt"
+# ... and with one candidate on the device at a time: every kernel's duration by itself, and the step breakdown
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_lanes1" -o bench -- python3 bench.py --no-cpu-baseline --lanes 1 > "$OUT/bench_lanes1_line.json" 2> "$OUT/bench_lanes1.err"
+python3 tools/trace_medians.py "$OUT/bench_lanes1" > "$OUT/bench_lanes1_medians.txt"
+python3 tools/stepbreakdown.py "$(find "$OUT/bench_lanes1" -name "*kernel_trace.csv" | head -1)" > "$OUT/sweep_step_breakdown.txt"
 # 3. HBM traffic: one counter per pass, nothing else traced
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 tools/kbench.py --iters 6 > "$OUT/pmc_fetch.log" 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 tools/kbench.py --iters 6 > "$OUT/pmc_write.log" 2>&1

@@ -346,7 +346,7 @@ STRONG_WORKLOAD = ("DeepLabV3Plus_resnet magnitude_taylor sensitivity sweep, ALL
                    "arg-max/confusion, KD-Lite loss) + all-reduce of the tables")
 
 
-def strong_mode(args, sweep, images, labels, dev, rank, world, tune_s, taylor_s, build_s, first_s):
+def strong_mode(args, sweep, images, labels, dev, rank, world, tune_s, taylor_s, build_s, first_s, lanes=1, lanes_s=0.0):
     """The whole sweep, wall-clock, max over ranks; rank 0 prints the JSON line."""
     w = whole_sweep(sweep, images, labels, dev, rank, world)
     result = {
@@ -359,12 +359,14 @@ def strong_mode(args, sweep, images, labels, dev, rank, world, tune_s, taylor_s,
         "config": {"workload": STRONG_WORKLOAD,
                    "num_classes": CLASSES, "eval_batch": [BATCH, 3, SIZE, SIZE], "candidates": w["candidates"],
                    "groups": len(sweep.groups), "ratios": list(DEFAULT_RATIOS),
-                   "parallelism": f"candidates sharded over {world} rank(s) by estimated cost (LPT)"},
+                   "parallelism": f"candidates sharded over {world} rank(s) by estimated cost (LPT); {lanes} candidate(s) "
+                                  "in flight per rank"},
         "sweep_s": w["sweep_s"], "ranks": w["ranks"],
         "setup": {"miopen_find_db_warmup_s": round(tune_s, 1), "model_build_s": round(build_s, 3),
                   "unpruned_first_forward_s": round(first_s, 3),
                   "taylor_calibration_s": round(taylor_s, 3), "taylor_batches": 2, "taylor_sharded": world > 1,
-                  "new_conv_problems_seen": w["new_conv_problems_looked_up"]},
+                  "new_conv_problems_seen": w["new_conv_problems_looked_up"], "lanes": lanes,
+                  "lanes_setup_s": round(lanes_s, 3)},
         "check": w["check"],
     }
     if rank == 0:
@@ -432,7 +434,10 @@ def main():
     sweep = SensitivitySweep(model, CLASSES, DEFAULT_RATIOS, ignored_layers=ignored,
                              autocast_dtype=None if args.fp32_forward else torch.float16)
     n_cand = len(sweep.candidates)
-    lanes = sweep.enable_lanes(args.lanes)
+    t_lanes = time.perf_counter()
+    lanes = sweep.enable_lanes(args.lanes)   # set-up like the construction of the sweep itself: copies of the network + their groups
+    torch.cuda.synchronize()
+    lanes_s = time.perf_counter() - t_lanes
     if args.strong:
         # per-process library initialisation, like the find-database warm-up: the first forward of the un-pruned
         # network at this geometry (MIOpen's first call per convolution problem, hipBLASLt plans, autocast copies)
@@ -441,7 +446,7 @@ def main():
             sweep.forward(images)
         torch.cuda.synchronize()
         first_s = time.perf_counter() - t_first
-        strong_mode(args, sweep, images, labels, dev, rank, world, tune_s, taylor_s, build_s, first_s)
+        strong_mode(args, sweep, images, labels, dev, rank, world, tune_s, taylor_s, build_s, first_s, lanes, lanes_s)
         return
     parts = sdist.partition_by_cost(sweep.candidate_costs(images), world)
     mine = parts[rank]
@@ -545,11 +550,12 @@ def main():
                                                  "the memory system with them"}},
         "setup": {"miopen_find_db_warmup_s": round(tune_s, 1), "timed_prepare_s": round(prep_s, 4), "warm_mode": args.warm_mode,
                   "new_conv_problems_seen": n_warm, "taylor_calibration_s": round(taylor_s, 3), "taylor_batches": 2,
+                  "lanes": lanes, "lanes_setup_s": round(lanes_s, 3),
                   "quota_layers": len(quotas), "gather_MB_per_candidate": round(moved / max(args.steps, 1) / 1e6, 2)},
     }
     if rank == 0 and not args.torch_forward and not args.fp32_forward:
         # candidates of the first lane: one after the other on the current stream
-        probe = [c for c in dict.fromkeys(todo[args.warmup:]) if c % lanes == 0][:8]
+        probe = [c for c in dict.fromkeys(todo[args.warmup:]) if sweep.lane_index(c) == 0][:8]
         result["forward_roofline"] = forward_probe(sweep, probe, images, labels, teacher, table, kd)
     if not args.no_strong_block:
         # The strong-scaling figure beside the weak one: the whole sweep, all candidates shared by the ranks, on a

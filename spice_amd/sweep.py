@@ -55,6 +55,7 @@ class SensitivitySweep:
                           ignored_layers=list(ignored_layers) if ignored_layers is not None else None,
                           autocast_dtype=autocast_dtype, kd_temperature=kd_temperature, kd_alpha=kd_alpha)
         self._lanes: List["SensitivitySweep"] = [self]
+        self._lane_assign: Dict[int, int] = {}   # candidate -> lane, dealt in the order candidates are first named
         self._stream: Optional[torch.cuda.Stream] = None   # lanes beyond the first: their own stream
         self.num_classes = num_classes
         self.autocast_dtype = autocast_dtype
@@ -168,8 +169,9 @@ class SensitivitySweep:
     # -- host preparation for a set of candidates: plans + one shared index upload
     # -- lanes: further copies of the network, each with its own launch plans and its own stream -------------
     def enable_lanes(self, count: int) -> int:
-        """Evaluate `count` candidates at a time: candidate i belongs to lane i % count, a copy of the network
-        with launch plans of its own, whose launches go to a stream of its own.  One host thread feeds all of
+        """Evaluate `count` candidates at a time: the candidates are dealt to `count` lanes in the order they are
+        first named (prepare / evaluate), a lane being a copy of the network with launch plans of its own, whose
+        launches go to a stream of its own.  One host thread feeds all of
         them; on the device the lanes' kernels fill each other's ramps, tails and half-empty launches (two
         processes sharing an MI355X evaluate 16 % more candidates per second than one; this is the same overlap
         without the second process).  Results are those of one lane: every candidate still runs the same kernels
@@ -198,10 +200,20 @@ class SensitivitySweep:
             lane._stream.wait_stream(torch.cuda.current_stream(self.device))
             self._lanes.append(lane)
         del self._lanes[count:]
+        self._lane_assign = {}
         return len(self._lanes)
 
+    def lane_index(self, index: int) -> int:
+        """The lane candidate `index` belongs to (dealt round-robin at its first mention, so that a rank's share is
+        spread evenly whatever its indices are)."""
+        k = self._lane_assign.get(index)
+        if k is None or k >= len(self._lanes):
+            k = len(self._lane_assign) % len(self._lanes)
+            self._lane_assign[index] = k
+        return k
+
     def _lane_of(self, index: int) -> "SensitivitySweep":
-        return self._lanes[index % len(self._lanes)]
+        return self._lanes[self.lane_index(index)] if len(self._lanes) > 1 else self
 
     @contextlib.contextmanager
     def lane_context(self, index: int):
@@ -227,9 +239,8 @@ class SensitivitySweep:
 
     def prepare(self, indices: Sequence[int]) -> None:
         if len(self._lanes) > 1:
-            n = len(self._lanes)
             for k, lane in enumerate(self._lanes):
-                lane._prepare([i for i in indices if i % n == k])
+                lane._prepare([i for i in indices if self.lane_index(i) == k])
         else:
             self._prepare(indices)
 
@@ -269,12 +280,12 @@ class SensitivitySweep:
         evaluation loop keeps full, and the loop ends up waiting for the helper.  Returns the number
         of problems warmed."""
         if len(self._lanes) > 1:   # each lane for its own candidates (its plans name its own copy's modules)
-            n = len(self._lanes)
             self._ensure_geometry(images)
             for lane in self._lanes[1:]:   # the copies see the same geometry: no forward of their own to learn it
                 lane._geometry = {m: self._geometry[t] for m, t in lane._twin_of.items() if t in self._geometry}
                 lane._geometry_for = self._geometry_for
-            return sum(lane._warm_shapes(images, [i for i in indices if i % n == k]) for k, lane in enumerate(self._lanes))
+            return sum(lane._warm_shapes(images, [i for i in indices if self.lane_index(i) == k])
+                       for k, lane in enumerate(self._lanes))
         return self._warm_shapes(images, indices)
 
     def _warm_shapes(self, images: torch.Tensor, indices: Sequence[int]) -> int:

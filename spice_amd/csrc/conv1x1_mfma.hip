@@ -1,34 +1,34 @@
-// 1x1 stride-1 convolution of fp16 NCHW activations with the inference batch-norm and the element-wise
+// Convolutions of fp16 NCHW activations on the matrix cores, with the inference batch-norm and the element-wise
 // tail of a residual block applied to the product before it leaves the compute unit:
-//   Y[n][Cout, HW] = relu?( bn( W[Cout, Cin] @ X[n][Cin, HW] ) [+ R | + bn_r(R)] )
-// one launch instead of a matrix product and a batch-norm pass over its result (the pairs of
-// pruning/models.py:35-39's networks: every bottleneck's conv1/bn1 and conv3/bn3, the ASPP branches and
-// projections).  The product is rounded to fp16 where the separate product would have stored it and the
-// tail is the arithmetic of bn_math.h, so the values are those of the two-launch route up to the order of
-// the fp32 sums.  mean == nullptr leaves the tail out (the plain product).
+//   Y[n][Cout, HW] = relu?( bn( W[Cout, K] @ X'[n][K, HW] ) [+ R | + bn_r(R)] )
+// one launch instead of a convolution and a batch-norm pass over its result (the layers of pruning/models.py:35-39's
+// networks: every bottleneck's conv1/bn1, conv2/bn2 and conv3/bn3, projection shortcuts, the stem, the ASPP branches
+// and projections).  X' is x itself (1x1), its even pixels (1x1, stride 2), nine shifted views of it (3x3: K = 9 Cin,
+// weights tap-major) or 49 shifted, column-halved views (7x7 stride 2: K = 49 Cin); the kernel picks them from x while
+// it stages it - no im2col buffer, no layout copies.  The product is rounded to fp16 where a separate convolution
+// would have stored it and the tail is the arithmetic of bn_math.h, so the values are those of the separate launches
+// up to the order of the fp32 sums.  mean == nullptr leaves the tail out (the plain product).
 //
-// These products are mostly bound by memory (Cin, Cout <= 2048 against 8K-128K pixels), so the kernel is
-// laid out for traffic first: X is read once per 128 output channels in 16-byte pieces, the product never
-// goes to memory in fp32 or un-normalised, the residual and Y move in 16-byte pieces.
-//
-// Workgroup: 256 lanes = 4 waves on a 128 or 256 (channels) x 64 (pixels of one image) tile, K in steps of 64.
-//   LDS   A[128 | 256][72]  weights, K contiguous (144-byte rows: a ds_read_b128 of 16 consecutive rows covers all 64 banks once)
-//         B[64][64]   activations as they lie in memory, pixels contiguous, 16-byte pieces XOR-swizzled by the row
-//   wave w owns channels 32 w .. +31 (or 64 w .. +63) and all 64 pixels: two (four) v_mfma_f32_32x32x16_f16 per 16 of K, with the PIXELS as
-//   the rows of the product (so that a lane ends up holding four consecutive pixels of one channel):
+// Tile: 128 (x MT) channels x 64 or 128 pixels of one image, K in steps of 64.
+//   LDS   A[128 MT][72]  weights, K contiguous (144-byte rows: a ds_read_b128 of 16 consecutive rows covers all 64 banks once)
+//         B[64][64] (x 2 side by side)  activations as they lie in memory, pixels contiguous, 16-byte pieces XOR-swizzled by the row
+//   v_mfma_f32_32x32x16_f16 with the PIXELS as the rows of the product (so that a lane ends up holding four consecutive
+//   pixels of one channel):
 //         A operand: lane l holds X^T[pixel l & 31][k = 8 (l >> 5) + 0..7]      two ds_read_b64_tr_b16, which hand each
 //                    lane a COLUMN of a 4 x 16 block of the pixel-contiguous image
 //         B operand: lane l holds W^T[k = 8 (l >> 5) + 0..7][channel l & 31]    one ds_read_b128 of a row of A
 //         result:    lane l holds channel l & 31, pixels (r & 3) + 8 (r >> 2) + 4 (l >> 5) in register r
-//   Epilogue: accumulators -> fp16 -> LDS C[128][72] (8-byte writes) -> row-major 16-byte pieces -> tail -> global.
+//   Global loads are buffer loads with 32-bit offsets; what lies outside an operand reads as zeros, so no load sits
+//   behind a branch.  Three forms (STAGES): 1 = four waves (32 MT channels x 64 pixels each), one LDS image, four
+//   workgroups per compute unit: many tiles, short K; 3 = eight waves (32 x 32 each), two LDS images, two register
+//   stages, one barrier per K step: deep K on one or two tiles per compute unit; 4 = the same on 128 pixels (32 x 64 per
+//   wave): deep K on many tiles.
+//   Epilogue: accumulators -> fp16 -> LDS C image (8-byte writes) -> row-major 16-byte pieces -> tail -> global.
 //   The residual's pieces are requested before the products start, so they have arrived when the tail needs them.
 #include "bn_math.h"
 
 namespace spice {
 
-#ifndef SPICE_FD1
-#define SPICE_FD1 1
-#endif
 constexpr int kMmThreads = 256;
 constexpr int kMmBM = 128, kMmBK = 64;   // channels per tile (x MT), K per step; pixels per tile: mm_tile_pixels
 constexpr int kMmAPitch = 72;    // halfs
@@ -55,7 +55,7 @@ struct MmArgs {
     int p_relu;
     int M, K, hw;           // hw: pixels per image of the PRODUCT
     int x_hw, x_w, y_w;     // stride 2 and 3x3: pixels per image and row width of x, row width of the product
-    int x_h, cin, stride, dil;   // 3x3 only: rows of x, its channels (K = 9 cin), stride (1 | 2) and dilation
+    int x_h, cin, stride, dil;   // 3x3 and 7x7: rows of x, its channels (K = 9 | 49 cin); 3x3: stride (1 | 2) and dilation
     int tiles_m, tiles_n;   // per image
     unsigned total_tiles;
     int relu;
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
 
     // one K step of the products: the operands of FD sub-steps of 16 are all requested from LDS before the first
     // product, in straight-line code, so that the reads of a sub-step overlap the products of the one before
-    constexpr int FD = (STAGES == 1 && MT == 1) ? SPICE_FD1 : 4;
+    constexpr int FD = (STAGES == 1 && MT == 1) ? 1 : 4;
     auto multiply_step = [&](int image) {
         if (!has_rows[0]) return;   // uniform per wave; rows of a later 32 beyond M are zeros in the A image
 #pragma unroll

@@ -19,10 +19,11 @@
 //         B operand: lane l holds W^T[k = 8 (l >> 5) + 0..7][channel l & 31]    one ds_read_b128 of a row of A
 //         result:    lane l holds channel l & 31, pixels (r & 3) + 8 (r >> 2) + 4 (l >> 5) in register r
 //   Global loads are buffer loads with 32-bit offsets; what lies outside an operand reads as zeros, so no load sits
-//   behind a branch.  Three forms (STAGES): 1 = four waves (32 MT channels x 64 pixels each), one LDS image, four
+//   behind a branch.  Four forms (STAGES): 1 = four waves (32 MT channels x 64 pixels each), one LDS image, four
 //   workgroups per compute unit: many tiles, short K; 3 = eight waves (32 x 32 each), two LDS images, two register
 //   stages, one barrier per K step: deep K on one or two tiles per compute unit; 4 = the same on 128 pixels (32 x 64 per
-//   wave): deep K on many tiles.
+//   wave): deep K on many tiles; 5 = eight waves (32 x 32 each) on 64 channels x 128 pixels: layers of at most 64
+//   output channels, which would leave half of a 128-channel tile's waves without rows.
 //   Epilogue: accumulators -> fp16 -> LDS C image (8-byte writes) -> row-major 16-byte pieces -> tail -> global.
 //   The residual's pieces are requested before the products start, so they have arrived when the tail needs them.
 #include "bn_math.h"
@@ -68,10 +69,12 @@ __device__ __forceinline__ unsigned mm_tile_of_block(unsigned id, unsigned total
     return (id & 7u) * (total >> 3) + (id >> 3);
 }
 
-// Pixels per tile of the forms: STAGES 1 (four waves) and 3 (eight waves) 64, STAGES 4 (eight waves) 128.
-constexpr int mm_tile_pixels(int stages) { return stages == 4 ? 128 : 64; }
+// Pixels per tile of the forms: STAGES 1 (four waves) and 3 (eight waves) 64, STAGES 4 and 5 (eight waves) 128.
+constexpr int mm_tile_pixels(int stages) { return stages >= 4 ? 128 : 64; }
+// Channels per tile: 128 (x MT), or 64 in form 5 (layers of at most 64 output channels: no half-empty tile).
+constexpr int mm_tile_channels(int stages, int mt) { return stages == 5 ? 64 : kMmBM * mt; }
 constexpr int mm_lds_bytes(int stages, int mt) {
-    return (stages > 1 ? 2 : 1) * (kMmBM * mt * kMmAPitch + kMmBK * mm_tile_pixels(stages)) * 2;
+    return (stages > 1 ? 2 : 1) * (mm_tile_channels(stages, mt) * kMmAPitch + kMmBK * mm_tile_pixels(stages)) * 2;
 }
 
 // Offset (halfs) of 16-byte piece `piece` (0..7) of row `k` of the B image.  Rows are 128 bytes, so rows k and
@@ -158,13 +161,14 @@ __device__ __forceinline__ uint4 mm_shift_halfs(uint4 v, int n) {
 
 template <int STAGES, int MT, int XMODE = kXPlain, bool PRE = false, bool W_ODD = false>
 __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ? 4 : 2) void conv1x1_bn_act_mfma_kernel(MmArgs a) {
-    constexpr int BM = kMmBM * MT;          // channels per workgroup: MT 32-channel product tiles per wave
+    constexpr int BM = mm_tile_channels(STAGES, MT);   // channels per workgroup: MT 32-channel product tiles per wave
+    constexpr int MW = BM / (32 * MT);      // waves along the channels; the others along the pixels
     // deep K: eight waves, a 32-channel x 32-pixel product each (twice the waves to hide each other's waits: these
     // launches leave a compute unit one or two workgroups); otherwise four waves with 32 MT channels x 64 pixels each
     constexpr int THREADS = STAGES > 1 ? 2 * kMmThreads : kMmThreads;
     constexpr int NPX = mm_tile_pixels(STAGES);   // pixels per tile: 64, or 128 as two 64-pixel sub-images side by side
     constexpr int PCS = NPX / 8;                  // 16-byte pieces per row of the X tile and of the product
-    constexpr int NT = (STAGES > 1 && NPX == 64) ? 1 : 2;   // 32-pixel blocks per wave
+    constexpr int NT = (STAGES == 3 || STAGES == 5) ? 1 : 2;   // 32-pixel blocks per wave
     constexpr int A_PIECES = BM * 8 / THREADS;            // 16-byte pieces of A per lane and K step
     constexpr int B_PIECES = kMmBK * PCS / THREADS;       // ... of X
     constexpr int ROWS = BM * PCS / THREADS;              // rows per lane in the row-major pass of the epilogue
@@ -434,9 +438,10 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
 
     // operand addresses inside the LDS images (halfs), without the K-step part
     const int h = lane >> 5;
-    const int wave_row = 32 * MT * (wave & 3);                            // first channel of the wave inside the tile
-    const int wave_px = NT == 1 ? wave >> 2 : 0;                          // first 32-pixel block of the wave ...
-    const int wave_sub = NPX == 128 ? wave >> 2 : 0;                      // ... inside this 64-pixel sub-image
+    const int wave_m = wave % MW, wave_n = wave / MW;                     // the wave's place along the channels / the pixels
+    const int wave_row = 32 * MT * wave_m;                                // first channel of the wave inside the tile
+    const int wave_px = NT == 1 ? wave_n & 1 : 0;                         // first 32-pixel block of the wave ...
+    const int wave_sub = NT == 1 ? wave_n >> 1 : wave_n;                  // ... inside this 64-pixel sub-image
     const int w_off = (wave_row + (lane & 31)) * kMmAPitch + 8 * h;       // + 32 mi rows + 16 s
     // transposed read: lane 4q + p of a 16-lane group supplies row q, pixels 4p .. 4p+3 of the group's 16 pixels
     const int g_b = (lane >> 4) & 1, g_q = (lane & 15) >> 2, g_p = lane & 3;
@@ -588,6 +593,8 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
 
 SPICE_ENV_KNOB(mm_stages_knob, "SPICE_CONV1X1_STAGES", 0)
 SPICE_ENV_KNOB(mm_mt_knob, "SPICE_CONV1X1_MT", 0)
+SPICE_ENV_KNOB(mm_m64_knob, "SPICE_CONV_M64", 1)
+SPICE_ENV_KNOB(mm_m64_min_k_knob, "SPICE_CONV_M64_MIN_K", 256)
 
 }  // namespace spice
 
@@ -664,9 +671,19 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
         else if (kdim >= 4 * kMmBK && tiles128 >= 2 * cus && (hw & 127) == 0) form = 4;
     }
     if (form == 4 && !has_wide_pixels) form = forced > 0 ? 3 : 1;
+    // A layer of at most 64 output channels fills half a 128-channel tile: half the waves of a workgroup have no
+    // rows.  Form 5 gives it 64-channel x 128-pixel tiles with all eight waves at work (a 32 x 32 product each):
+    // 31.3 against 36.7 us for layer1's 3x3 convolutions, level for the 1x1 products of K = 256, slower for one K step
+    // (10.5 against 10.2 us) and for the stem's 7x7 mode (67.3 against 63.2 us), which therefore stay (SPICE_CONV_M64=2
+    // sends the stem there too).
+    const long m64 = mm_m64_knob();
+    if (m64 != 0 && cout <= 64 && (hw & 127) == 0 && kdim >= mm_m64_min_k_knob() && (has_wide_pixels || c7) &&
+        (c7 ? m64 >= 2 : (kdim & 1) == 0) && (forced == 0 || forced == 5))
+        form = 5;
     const bool deep = form >= 3;
-    const int64_t tiles_n = ceil_div(hw, form == 4 ? 128 : 64);
-    if (tiles_m * tiles_n > INT32_MAX / n) return SPICE_ERR_UNSUPPORTED;
+    const int64_t tiles_m_used = form == 5 ? ceil_div(cout, 64) : tiles_m;
+    const int64_t tiles_n = ceil_div(hw, form >= 4 ? 128 : 64);
+    if (tiles_m_used * tiles_n > INT32_MAX / n) return SPICE_ERR_UNSUPPORTED;
     MmArgs a;
     a.x = static_cast<const _Float16 *>(x);
     a.w = static_cast<const _Float16 *>(weight);
@@ -700,13 +717,15 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     a.cin = static_cast<int>(cin);
     a.stride = c3_stride;
     a.dil = c3_dil;
-    a.tiles_m = static_cast<int>(tiles_m);
+    a.tiles_m = static_cast<int>(tiles_m_used);
     a.tiles_n = static_cast<int>(tiles_n);
-    a.total_tiles = static_cast<unsigned>(tiles_m * tiles_n * n);
+    a.total_tiles = static_cast<unsigned>(tiles_m_used * tiles_n * n);
     a.relu = relu ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (c7) {
-        if (kdim & 1) mm_launch<1, 1, kX7x7S2, false, true>(a, st);
+        if (form == 5 && (kdim & 1)) mm_launch<5, 1, kX7x7S2, false, true>(a, st);
+        else if (form == 5) mm_launch<5, 1, kX7x7S2>(a, st);
+        else if (kdim & 1) mm_launch<1, 1, kX7x7S2, false, true>(a, st);
         else mm_launch<1, 1, kX7x7S2>(a, st);
     } else if (kdim & 1) {   // pruned to an odd number of input channels: the forms that take rows of W from the middle of a dword
         if (c3 && c3_stride == 2) mm_launch<1, 1, kX3x3S2, false, true>(a, st);
@@ -718,7 +737,8 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
         if (deep) mm_launch<3, 1, kX3x3S2>(a, st);
         else mm_launch<1, 1, kX3x3S2>(a, st);
     } else if (c3) {
-        if (form == 4) mm_launch<4, 1, kX3x3>(a, st);
+        if (form == 5) mm_launch<5, 1, kX3x3>(a, st);
+        else if (form == 4) mm_launch<4, 1, kX3x3>(a, st);
         else if (deep) mm_launch<3, 1, kX3x3>(a, st);
         else mm_launch<1, 1, kX3x3>(a, st);
     } else if (p_mean != nullptr) {
@@ -729,6 +749,8 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
         else mm_launch<1, 1, kXStride2>(a, st);
     } else if (wide) {
         mm_launch<1, 2>(a, st);
+    } else if (form == 5) {
+        mm_launch<5, 1>(a, st);
     } else if (form == 4) {
         mm_launch<4, 1>(a, st);
     } else if (deep) {

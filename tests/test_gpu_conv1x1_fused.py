@@ -44,7 +44,9 @@ SHAPES = [(2, 64, 16, 16, 256), (1, 40, 8, 24, 130), (3, 230, 4, 6, 77), (1, 8, 
           # deep K on two 128-channel tiles per compute unit: the eight-wave form with 256-channel tiles, K tail
           (8, 264, 32, 32, 512),
           # deep K on many tiles: the eight-wave form with 128-pixel tiles; M tail and K tail
-          (8, 264, 64, 64, 300), (8, 512, 32, 32, 512)]
+          (8, 264, 64, 64, 300), (8, 512, 32, 32, 512),
+          # at most 64 output channels on whole 128-pixel tiles: the 64-channel form; one K step, K tail + M tail
+          (8, 64, 64, 64, 64), (2, 200, 16, 16, 33)]
 
 
 def _integer_case(shape, dev):

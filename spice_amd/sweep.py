@@ -418,6 +418,11 @@ class SensitivitySweep:
             dev_sync()
             ph["teacher_forward_s"], t = time.perf_counter() - t, time.perf_counter()
             self.fork_lanes()
+            for lane in self._lanes[1:]:
+                # one forward of the un-pruned copy on the lane's stream: its allocator pool and its fp16 copies of the
+                # weights exist before the first candidate needs them (a first allocation stalls every stream)
+                with torch.cuda.stream(lane._stream):
+                    lane.forward(images)
             for i in mine:   # no communication before the final all-reduce
                 self.evaluate(i, images, labels, teacher, table[i], kd[i] if with_kd else None)
             self.join_lanes()

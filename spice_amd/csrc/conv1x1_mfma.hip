@@ -264,21 +264,24 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
     // piece is to be shifted when stored.
     constexpr int RS = DEEP ? 2 : 1;   // register stages: K steps whose pieces are in flight
     uint4 ra_all[RS][A_PIECES], rb_all[RS][B_PIECES];
+    unsigned ra_hi_all[RS][W_ODD ? A_PIECES : 1];   // odd K: the dword behind each piece of A (see load_step)
     int rb_meta_all[RS][B_PIECES];
     auto as_uint4 = [](u32x4_t v) { return make_uint4(v.x, v.y, v.z, v.w); };
-    auto load_step = [&](int k0, uint4 (&ra)[A_PIECES], uint4 (&rb)[B_PIECES], int (&rb_meta)[B_PIECES]) {
+    auto load_step = [&](int k0, auto stage) {
+        constexpr int S = decltype(stage)::value;
+        auto &ra = ra_all[S];
+        auto &rb = rb_all[S];
+        auto &rb_meta = rb_meta_all[S];
+        [[maybe_unused]] auto &ra_hi = ra_hi_all[S];
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
             const int off = a_off[i] + 2 * k0;
             if constexpr (W_ODD) {
                 // odd K: every other row of W starts in the middle of a dword.  The range check of a buffer load is
                 // per dword as addressed, so a dword that starts on W's last half would be dropped with it: read
-                // whole aligned dwords, one more than the piece, and move the bytes down
-                const u32x4_t lo = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, off & ~3, 0, 0);
-                const unsigned hi = __builtin_amdgcn_raw_buffer_load_b32(w_rsrc, (off & ~3) + 16, 0, 0);
-                const unsigned sh = static_cast<unsigned>(off) & 2u;
-                ra[i] = make_uint4(__builtin_amdgcn_alignbyte(lo.y, lo.x, sh), __builtin_amdgcn_alignbyte(lo.z, lo.y, sh),
-                                   __builtin_amdgcn_alignbyte(lo.w, lo.z, sh), __builtin_amdgcn_alignbyte(hi, lo.w, sh));
+                // whole aligned dwords, one more than the piece; store_step moves the bytes down
+                ra[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, off & ~3, 0, 0));
+                ra_hi[i] = __builtin_amdgcn_raw_buffer_load_b32(w_rsrc, (off & ~3) + 16, 0, 0);
             } else {
                 ra[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, off, 0, 0));
             }
@@ -390,12 +393,22 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
             }
         }
     };
-    auto store_step = [&](int k0, const uint4 (&ra)[A_PIECES], const uint4 (&rb)[B_PIECES], const int (&rb_meta)[B_PIECES], int image) {
+    auto store_step = [&](int k0, auto stage, int image) {
+        constexpr int S = decltype(stage)::value;
+        const auto &ra = ra_all[S];
+        const auto &rb = rb_all[S];
+        const auto &rb_meta = rb_meta_all[S];
+        [[maybe_unused]] const auto &ra_hi = ra_hi_all[S];
         const bool k_ends_inside = k0 + kMmBK > a.K;   // uniform; only the last step of a K that is no multiple of 64
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
             const int c = tid + THREADS * i;
             uint4 piece = ra[i];
+            if constexpr (W_ODD) {
+                const unsigned sh = static_cast<unsigned>(a_off[i]) & 2u;   // 2 k0 is a multiple of 4
+                piece = make_uint4(__builtin_amdgcn_alignbyte(piece.y, piece.x, sh), __builtin_amdgcn_alignbyte(piece.z, piece.y, sh),
+                                   __builtin_amdgcn_alignbyte(piece.w, piece.z, sh), __builtin_amdgcn_alignbyte(ra_hi[i], piece.w, sh));
+            }
             if (k_ends_inside) {   // columns from K on are the next row's: keep the first K - k halfs
                 const int keep = a.K - (k0 + (c & 7) * 8);
                 if (keep < 8) piece = keep <= 0 ? make_uint4(0, 0, 0, 0) : mm_shift_halfs(mm_shift_halfs(piece, 8 - keep), keep - 8);
@@ -485,8 +498,8 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
         }
     };
 
-    load_step(0, ra_all[0], rb_all[0], rb_meta_all[0]);
-    if constexpr (DEEP) load_step(kMmBK, ra_all[1], rb_all[1], rb_meta_all[1]);
+    load_step(0, std::integral_constant<int, 0>{});
+    if constexpr (DEEP) load_step(kMmBK, std::integral_constant<int, 1>{});
     // the residual's pieces, requested behind the first K steps'
     if (has_res) {
 #pragma unroll
@@ -505,15 +518,15 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
         // step.  Nothing in the body is conditional - loads beyond K read the operands' first bytes, stores beyond K
         // write zeros into an image nobody reads - so the compiler counts the loads a store may leave in flight.
         if constexpr (PRE) __syncthreads();   // the pending batch-norm's parameters are in LDS
-        store_step(0, ra_all[0], rb_all[0], rb_meta_all[0], 0);
-        load_step(2 * kMmBK, ra_all[0], rb_all[0], rb_meta_all[0]);
+        store_step(0, std::integral_constant<int, 0>{}, 0);
+        load_step(2 * kMmBK, std::integral_constant<int, 0>{});
         __syncthreads();
         auto deep_step = [&](int t, auto parity) {
             constexpr int P = decltype(parity)::value;   // t & 1
             multiply_step(P * IMG);
             __builtin_amdgcn_sched_barrier(0);   // the stores wait for loads: not before the products
-            store_step((t + 1) * kMmBK, ra_all[1 - P], rb_all[1 - P], rb_meta_all[1 - P], (1 - P) * IMG);
-            load_step((t + 3) * kMmBK, ra_all[1 - P], rb_all[1 - P], rb_meta_all[1 - P]);
+            store_step((t + 1) * kMmBK, std::integral_constant<int, 1 - P>{}, (1 - P) * IMG);
+            load_step((t + 3) * kMmBK, std::integral_constant<int, 1 - P>{});
             __syncthreads();
         };
         int t = 0;
@@ -525,9 +538,9 @@ __global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ?
     } else {
         for (int t = 0; t < n_steps; ++t) {
             __syncthreads();   // every wave has read the previous step's image
-            store_step(t * kMmBK, ra_all[0], rb_all[0], rb_meta_all[0], 0);
+            store_step(t * kMmBK, std::integral_constant<int, 0>{}, 0);
             __syncthreads();
-            if (t + 1 < n_steps) load_step((t + 1) * kMmBK, ra_all[0], rb_all[0], rb_meta_all[0]);   // in flight from here
+            if (t + 1 < n_steps) load_step((t + 1) * kMmBK, std::integral_constant<int, 0>{});   // in flight from here
             multiply_step(0);
         }
     }

@@ -435,7 +435,11 @@ def main():
                              autocast_dtype=None if args.fp32_forward else torch.float16)
     n_cand = len(sweep.candidates)
     t_lanes = time.perf_counter()
-    lanes = sweep.enable_lanes(args.lanes)   # set-up like the construction of the sweep itself: copies of the network + their groups
+    try:   # set-up like the construction of the sweep itself: copies of the network + their groups
+        lanes = sweep.enable_lanes(args.lanes)
+    except Exception as e:   # the sweep still runs, one candidate at a time
+        print(f"[bench] lanes not available ({e}); one candidate at a time", file=sys.stderr, flush=True)
+        lanes = sweep.enable_lanes(1)
     torch.cuda.synchronize()
     lanes_s = time.perf_counter() - t_lanes
     if args.strong:
@@ -564,7 +568,7 @@ def main():
         # cost tens of microseconds instead of ~0.4 ms each (at most 70 candidates' worth per rank).
         fresh = SensitivitySweep(model, CLASSES, DEFAULT_RATIOS, ignored_layers=ignored,
                                  autocast_dtype=None if args.fp32_forward else torch.float16)
-        fresh.enable_lanes(args.lanes)
+        fresh.enable_lanes(lanes)
         w = whole_sweep(fresh, images, labels, dev, rank, world)
         w["scaling"] = "strong"
         w["workload"] = STRONG_WORKLOAD

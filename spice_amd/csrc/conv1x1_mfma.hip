@@ -19,11 +19,12 @@
 //         B operand: lane l holds W^T[k = 8 (l >> 5) + 0..7][channel l & 31]    one ds_read_b128 of a row of A
 //         result:    lane l holds channel l & 31, pixels (r & 3) + 8 (r >> 2) + 4 (l >> 5) in register r
 //   Global loads are buffer loads with 32-bit offsets; what lies outside an operand reads as zeros, so no load sits
-//   behind a branch.  Four forms (STAGES): 1 = four waves (32 MT channels x 64 pixels each), one LDS image, four
+//   behind a branch.  Five forms (STAGES): 1 = four waves (32 MT channels x 64 pixels each), one LDS image, four
 //   workgroups per compute unit: many tiles, short K; 3 = eight waves (32 x 32 each), two LDS images, two register
 //   stages, one barrier per K step: deep K on one or two tiles per compute unit; 4 = the same on 128 pixels (32 x 64 per
 //   wave): deep K on many tiles; 5 = eight waves (32 x 32 each) on 64 channels x 128 pixels: layers of at most 64
-//   output channels, which would leave half of a 128-channel tile's waves without rows.
+//   output channels, which would leave half of a 128-channel tile's waves without rows; 6 = sixteen waves (32 x 32
+//   each) on 128 channels x 128 pixels: deep K where such tiles make one round of the compute units.
 //   Epilogue: accumulators -> fp16 -> LDS C image (8-byte writes) -> row-major 16-byte pieces -> tail -> global.
 //   The residual's pieces are requested before the products start, so they have arrived when the tail needs them.
 #include "bn_math.h"
@@ -69,8 +70,10 @@ __device__ __forceinline__ unsigned mm_tile_of_block(unsigned id, unsigned total
     return (id & 7u) * (total >> 3) + (id >> 3);
 }
 
-// Pixels per tile of the forms: STAGES 1 (four waves) and 3 (eight waves) 64, STAGES 4 and 5 (eight waves) 128.
+// Pixels per tile of the forms: STAGES 1 (four waves) and 3 (eight waves) 64, STAGES 4, 5 (eight waves) and 6 (sixteen) 128.
 constexpr int mm_tile_pixels(int stages) { return stages >= 4 ? 128 : 64; }
+// Lanes per workgroup
+constexpr int mm_threads(int stages) { return stages == 6 ? 4 * kMmThreads : (stages > 1 ? 2 * kMmThreads : kMmThreads); }
 // Channels per tile: 128 (x MT), or 64 in form 5 (layers of at most 64 output channels: no half-empty tile).
 constexpr int mm_tile_channels(int stages, int mt) { return stages == 5 ? 64 : kMmBM * mt; }
 constexpr int mm_lds_bytes(int stages, int mt) {
@@ -160,15 +163,16 @@ __device__ __forceinline__ uint4 mm_shift_halfs(uint4 v, int n) {
 }
 
 template <int STAGES, int MT, int XMODE = kXPlain, bool PRE = false, bool W_ODD = false>
-__global__ __launch_bounds__(STAGES > 1 ? 2 * kMmThreads : kMmThreads, MT == 1 ? 4 : 2) void conv1x1_bn_act_mfma_kernel(MmArgs a) {
+__global__ __launch_bounds__(mm_threads(STAGES), MT == 1 ? 4 : 2) void conv1x1_bn_act_mfma_kernel(MmArgs a) {
     constexpr int BM = mm_tile_channels(STAGES, MT);   // channels per workgroup: MT 32-channel product tiles per wave
     constexpr int MW = BM / (32 * MT);      // waves along the channels; the others along the pixels
-    // deep K: eight waves, a 32-channel x 32-pixel product each (twice the waves to hide each other's waits: these
-    // launches leave a compute unit one or two workgroups); otherwise four waves with 32 MT channels x 64 pixels each
-    constexpr int THREADS = STAGES > 1 ? 2 * kMmThreads : kMmThreads;
+    // deep K: eight waves (sixteen in form 6), a 32-channel x 32-pixel product each (twice the waves to hide each other's
+    // waits: these launches leave a compute unit one or two workgroups); otherwise four waves with 32 MT channels x 64
+    // pixels each
+    constexpr int THREADS = mm_threads(STAGES);
     constexpr int NPX = mm_tile_pixels(STAGES);   // pixels per tile: 64, or 128 as two 64-pixel sub-images side by side
     constexpr int PCS = NPX / 8;                  // 16-byte pieces per row of the X tile and of the product
-    constexpr int NT = (STAGES == 3 || STAGES == 5) ? 1 : 2;   // 32-pixel blocks per wave
+    constexpr int NT = (STAGES == 3 || STAGES == 5 || STAGES == 6) ? 1 : 2;   // 32-pixel blocks per wave
     constexpr int A_PIECES = BM * 8 / THREADS;            // 16-byte pieces of A per lane and K step
     constexpr int B_PIECES = kMmBK * PCS / THREADS;       // ... of X
     constexpr int ROWS = BM * PCS / THREADS;              // rows per lane in the row-major pass of the epilogue
@@ -608,6 +612,7 @@ SPICE_ENV_KNOB(mm_stages_knob, "SPICE_CONV1X1_STAGES", 0)
 SPICE_ENV_KNOB(mm_mt_knob, "SPICE_CONV1X1_MT", 0)
 SPICE_ENV_KNOB(mm_m64_knob, "SPICE_CONV_M64", 1)
 SPICE_ENV_KNOB(mm_m64_min_k_knob, "SPICE_CONV_M64_MIN_K", 256)
+SPICE_ENV_KNOB(mm_w16_knob, "SPICE_CONV_W16", 1)
 
 }  // namespace spice
 
@@ -621,7 +626,7 @@ static void mm_launch(const spice::MmArgs &a, hipStream_t st) {
     const auto kernel = conv1x1_bn_act_mfma_kernel<STAGES, MT, XMODE, PRE, W_ODD>;
     if constexpr (bytes > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    hipLaunchKernelGGL(kernel, dim3(a.total_tiles), dim3(STAGES > 1 ? 2 * kMmThreads : kMmThreads), bytes, st, a);
+    hipLaunchKernelGGL(kernel, dim3(a.total_tiles), dim3(mm_threads(STAGES)), bytes, st, a);
 }
 
 constexpr int32_t kStem7x7 = -7;   // conv1x1_launch's c3_stride for the 7x7 stride-2 mode
@@ -676,13 +681,22 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     const bool has_wide_pixels = p_mean == nullptr && !(x_h > 0 && !c3) && !(c3 && c3_stride == 2);   // forms with a 128-pixel variant
     int form = 1;
     if (!wide && (kdim & 1) == 0 && !c7) {
-        if (forced > 0) form = forced >= 4 ? 4 : (forced >= 3 ? 3 : 1);
+        if (forced > 0) form = forced == 6 ? 6 : (forced >= 4 ? 4 : (forced >= 3 ? 3 : 1));
         else if (kdim >= 4 * kMmBK && tiles64 <= 2 * cus)
             // a plain or paired 1x1 product with K >= 512 gains from the wider tile as soon as every compute unit
             // gets one (2048 -> 512 on 8,192 pixels: 25.8 against 28.5 us); the 3x3 mode does not (24.1 against 22.4)
             form = (!c3 && kdim >= 8 * kMmBK && tiles128 >= cus && (hw & 127) == 0) ? 4 : 3;
         else if (kdim >= 4 * kMmBK && tiles128 >= 2 * cus && (hw & 127) == 0) form = 4;
     }
+    // One round of 128-pixel tiles (between three quarters of the compute units and all of them): sixteen waves on the
+    // tile (form 6), a 32 x 32 product each - the traffic of the 128-pixel form with the waves of two 64-pixel
+    // workgroups to hide its waits.  58.6 against 63.1 us for the dilated 512 -> 512 3x3 convolution, 20.5 against
+    // 22.4 us for 128 -> 128 on 32,768 pixels; level with form 4 on the 1x1 products it takes from it; slower wherever
+    // the tiles make half a round or several (SPICE_CONV_W16=0 switches it off).
+    if (forced == 0 && mm_w16_knob() != 0 && form >= 3 && cout > 64 && (hw & 127) == 0 && has_wide_pixels && !c7 &&
+        (kdim & 1) == 0 && 4 * tiles128 >= 3 * cus && tiles128 <= cus)
+        form = 6;
+    if (form == 6 && !has_wide_pixels) form = 4;
     if (form == 4 && !has_wide_pixels) form = forced > 0 ? 3 : 1;
     // A layer of at most 64 output channels fills half a 128-channel tile: half the waves of a workgroup have no
     // rows.  Form 5 gives it 64-channel x 128-pixel tiles with all eight waves at work (a 32 x 32 product each):
@@ -750,7 +764,8 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
         if (deep) mm_launch<3, 1, kX3x3S2>(a, st);
         else mm_launch<1, 1, kX3x3S2>(a, st);
     } else if (c3) {
-        if (form == 5) mm_launch<5, 1, kX3x3>(a, st);
+        if (form == 6) mm_launch<6, 1, kX3x3>(a, st);
+        else if (form == 5) mm_launch<5, 1, kX3x3>(a, st);
         else if (form == 4) mm_launch<4, 1, kX3x3>(a, st);
         else if (deep) mm_launch<3, 1, kX3x3>(a, st);
         else mm_launch<1, 1, kX3x3>(a, st);
@@ -762,6 +777,8 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
         else mm_launch<1, 1, kXStride2>(a, st);
     } else if (wide) {
         mm_launch<1, 2>(a, st);
+    } else if (form == 6) {
+        mm_launch<6, 1>(a, st);
     } else if (form == 5) {
         mm_launch<5, 1>(a, st);
     } else if (form == 4) {

@@ -45,6 +45,8 @@ SHAPES = [(2, 64, 16, 16, 256), (1, 40, 8, 24, 130), (3, 230, 4, 6, 77), (1, 8, 
           (8, 264, 32, 32, 512),
           # deep K on many tiles: the eight-wave form with 128-pixel tiles; M tail and K tail
           (8, 264, 64, 64, 300), (8, 512, 32, 32, 512),
+          # deep K on one round of 128-pixel tiles (192 and 256 of them): the sixteen-wave form; M tail and K tail
+          (8, 264, 64, 64, 100), (6, 512, 32, 32, 512),
           # at most 64 output channels on whole 128-pixel tiles: the 64-channel form; one K step, K tail + M tail
           (8, 64, 64, 64, 64), (2, 200, 16, 16, 33)]
 

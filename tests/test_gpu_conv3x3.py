@@ -40,7 +40,9 @@ CASES = [(2, 16, 8, 16, 24, 1, 1), (1, 64, 16, 16, 64, 1, 1), (1, 40, 8, 8, 130,
          # the eight-wave forms: 256-channel tiles (two 128-channel tiles per compute unit), and 128-channel tiles with a K tail
          (8, 32, 32, 32, 512, 1, 1), (4, 40, 32, 32, 256, 1, 2),
          # ... and 128-pixel tiles (deep K, many tiles), M tail
-         (8, 32, 64, 64, 130, 1, 1)]
+         (8, 32, 64, 64, 130, 1, 1),
+         # one round of 128-pixel tiles: the sixteen-wave form; M tail, K tail, dilation
+         (8, 32, 64, 64, 128, 1, 1), (6, 40, 64, 64, 100, 1, 2)]
 
 
 @pytest.mark.parametrize("case", CASES)

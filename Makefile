@@ -16,7 +16,7 @@ TORCH_CXXFLAGS := -O2 -fPIC -std=c++17 -Wall -Wno-unused-function -D__HIP_PLATFO
 
 all: $(LIB) $(TORCH_LIB)
 
-build/%.o: spice_amd/csrc/%.hip spice_amd/csrc/common.h spice_amd/csrc/bn_math.h include/spice_amd.h
+build/%.o: spice_amd/csrc/%.hip $(wildcard spice_amd/csrc/*.h) include/spice_amd.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

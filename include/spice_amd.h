@@ -167,6 +167,26 @@ int spice_kdlite_forward(const float *student, const float *teacher, const int64
                          float coef_ce, float coef_kd, const float *upstream,
                          void *workspace, size_t workspace_bytes, void *stream);
 
+/* The tail of a sensitivity-sweep candidate in ONE launch: the segmentation head's bilinear
+ * up-sampling (`nn.UpsamplingBilinear2d` at the end of the models of pruning/models.py:35-39), the
+ * KD-Lite loss of the up-sampled logits against the teacher's (pruning/losses.py:127-162) and the
+ * arg-max + confusion-matrix update (baseline/eval/inference.py:47-48, baseline/eval/metrics.py:8-26),
+ * without the full-size student logits ever being written: `low` [N,C,in_h,in_w] fp16 is
+ * interpolated on the fly with the arithmetic of spice_upsample_bilinear (same bits), so
+ *   out3 = spice_kdlite_forward(up(low), teacher, labels) and conf += histogram(labels, argmax up(low)).
+ * teacher [N,C,H,W] fp32, labels [N,H,W] int64, out3 3 floats, conf [C,C] int64 (+=).  The two
+ * workspaces are those of spice_kdlite_forward and spice_confusion_update (same sizes, same
+ * rules).  align_corners / scale_h / scale_w as spice_upsample_bilinear.
+ * SPICE_ERR_UNSUPPORTED (nothing launched; use the three separate calls) for the boundary and
+ * confidence options, W % 4 != 0, in_w % 8 != 0, pointers off 16 bytes, or source rows too long
+ * for the LDS stage. */
+int spice_sweep_head_f16(const void *low, const float *teacher, const int64_t *labels, int64_t n,
+                         int64_t c, int64_t in_h, int64_t in_w, int64_t h, int64_t w,
+                         int32_t align_corners, float scale_h, float scale_w,
+                         const spice_kdlite_params *params, float *out3, int64_t *conf,
+                         void *kd_workspace, size_t kd_workspace_bytes, void *conf_workspace,
+                         size_t conf_workspace_bytes, void *stream);
+
 /* x[i] *= *scale for i < n, skipped entirely on the device when *scale == 1. */
 int spice_scale_inplace(float *x, int64_t n, const float *scale, void *stream);
 

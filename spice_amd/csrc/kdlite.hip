@@ -12,6 +12,10 @@
 // Sums over pixels are carried in fp64 from the thread level up and combined in a fixed
 // order (thread -> wave butterfly -> workgroup -> one finalising workgroup): deterministic.
 #include "common.h"
+#include "bilinear_math.h"
+#include "conf_tail.h"
+
+#include <hip/hip_fp16.h>
 
 #include <stdlib.h>
 
@@ -340,44 +344,10 @@ struct PixStats {
     float ms[VEC], mt[VEC], zs[VEC], z1[VEC], zt[VEC], zt1[VEC], at[VEC], sy[VEC];
 };
 
-// Fold U class planes (c0..c0+U-1) into the running softmax statistics of VEC pixels.
-// FULL = all U classes exist; otherwise loads are clamped to the last class and the surplus
-// values replaced by a large negative fill (their exponentials are exactly zero).
-// sv / tv receive the raw logits of the step (the caller of the register-resident gradient pass
-// keeps them; everyone else passes scratch arrays).
-// STAGE: the raw logits are also parked in LDS (slot (2c+which)*threads + tid, touched by this
-// thread only) for the gradient pass.
-template <int VEC, int U, bool FULL, bool CONF, bool STAGE>
-__device__ __forceinline__ void kd_fold(PixStats<VEC> &st, const float *__restrict__ s_img,
-                                        const float *__restrict__ t_img, long long HW, int r,
-                                        int c0, int C, const int (&id)[VEC], float k2,
-                                        typename VecF<VEC>::type *stage, float (&sv)[U][VEC],
-                                        float (&tv)[U][VEC]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int cc = FULL ? c0 + u : min(c0 + u, C - 1);
-        load_vec_nt<VEC>(s_img + (long long)cc * HW + r, sv[u]);
-        load_vec_nt<VEC>(t_img + (long long)cc * HW + r, tv[u]);
-    }
-    if (STAGE) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!FULL && c0 + u >= C) break;
-            store_vec<VEC>(reinterpret_cast<float *>(stage + (2 * (c0 + u)) * kKdThreads + threadIdx.x), sv[u]);
-            store_vec<VEC>(reinterpret_cast<float *>(stage + (2 * (c0 + u) + 1) * kKdThreads + threadIdx.x), tv[u]);
-        }
-    }
-    if (!FULL) {
-#pragma unroll
-        for (int u = 1; u < U; ++u) {
-            const bool gone = c0 + u >= C;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                sv[u][e] = gone ? kNegFill : sv[u][e];
-                tv[u][e] = gone ? kNegFill : tv[u][e];
-            }
-        }
-    }
+// Fold the U class planes c0..c0+U-1, whose logits are in sv / tv, into the running statistics.
+template <int VEC, int U, bool CONF>
+__device__ __forceinline__ void kd_fold_stats(PixStats<VEC> &st, const float (&sv)[U][VEC], const float (&tv)[U][VEC],
+                                              int c0, const int (&id)[VEC], float k2) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         float msn = fmaxf(fmaxf(st.ms[e], fmaxf(sv[0][e], sv[1 % U][e])), fmaxf(sv[2 % U][e], sv[3 % U][e]));
@@ -418,6 +388,47 @@ __device__ __forceinline__ void kd_fold(PixStats<VEC> &st, const float *__restri
         st.zt1[e] = Zt1;
         st.sy[e] = sy;
     }
+}
+
+// Fold U class planes (c0..c0+U-1) into the running softmax statistics of VEC pixels.
+// FULL = all U classes exist; otherwise loads are clamped to the last class and the surplus
+// values replaced by a large negative fill (their exponentials are exactly zero).
+// sv / tv receive the raw logits of the step (the caller of the register-resident gradient pass
+// keeps them; everyone else passes scratch arrays).
+// STAGE: the raw logits are also parked in LDS (slot (2c+which)*threads + tid, touched by this
+// thread only) for the gradient pass.
+template <int VEC, int U, bool FULL, bool CONF, bool STAGE>
+__device__ __forceinline__ void kd_fold(PixStats<VEC> &st, const float *__restrict__ s_img,
+                                        const float *__restrict__ t_img, long long HW, int r,
+                                        int c0, int C, const int (&id)[VEC], float k2,
+                                        typename VecF<VEC>::type *stage, float (&sv)[U][VEC],
+                                        float (&tv)[U][VEC]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int cc = FULL ? c0 + u : min(c0 + u, C - 1);
+        load_vec_nt<VEC>(s_img + (long long)cc * HW + r, sv[u]);
+        load_vec_nt<VEC>(t_img + (long long)cc * HW + r, tv[u]);
+    }
+    if (STAGE) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!FULL && c0 + u >= C) break;
+            store_vec<VEC>(reinterpret_cast<float *>(stage + (2 * (c0 + u)) * kKdThreads + threadIdx.x), sv[u]);
+            store_vec<VEC>(reinterpret_cast<float *>(stage + (2 * (c0 + u) + 1) * kKdThreads + threadIdx.x), tv[u]);
+        }
+    }
+    if (!FULL) {
+#pragma unroll
+        for (int u = 1; u < U; ++u) {
+            const bool gone = c0 + u >= C;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                sv[u][e] = gone ? kNegFill : sv[u][e];
+                tv[u][e] = gone ? kNegFill : tv[u][e];
+            }
+        }
+    }
+    kd_fold_stats<VEC, U, CONF>(st, sv, tv, c0, id, k2);
 }
 
 // Gradient of four class planes: softmax probabilities recomputed from the final statistics.
@@ -533,6 +544,47 @@ __device__ __forceinline__ void kd_finalize(const double *partial, int n_blocks,
         out3[1] = (float)ce;
         out3[2] = (float)kd;
     }
+}
+
+// Hand a workgroup's eight partial sums to whichever workgroup arrives last, which folds all of them
+// and writes the loss.  The sums are stored write-through (agent-scope atomic stores), so no release
+// fence is needed; the storing wave drains them, one lane takes a ticket, and the last arriver
+// acquires before reading.
+__device__ __forceinline__ void kd_publish_and_finalize(const KdArgs &a, const double (&out8)[8],
+                                                        double (*red)[8]) {
+    const int tid = threadIdx.x;
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double v = wave_sum(out8[k]);
+            if (lane == 0) red[wave][k] = v;
+        }
+        __syncthreads();
+        if (tid < 8) {
+            double v = 0.0;
+            for (int wv = 0; wv < kKdThreads / 64; ++wv) v += red[wv][tid];
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.main_partial) + (long long)blockIdx.x * 8 + tid,
+                               (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __shared__ int last_flag;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == gridDim.x - 1);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        last_flag = last;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    kd_finalize(a.main_partial, (int)gridDim.x, a.totals, a.out3, a.T, a.alpha, a.bw, a.conf);
+    if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // STAGE (gradient only): the tile's logits are parked in dynamic LDS during the statistics pass
@@ -689,41 +741,7 @@ __device__ __forceinline__ void kd_main_body(const KdArgs &a) {
     double out8[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) out8[k] = (k < (EXT ? 8 : 4)) ? acc[k % (EXT ? 8 : 4)] : 0.0;
-    // Hand the partial sums to whichever workgroup arrives last.  The eight sums are stored
-    // write-through (agent-scope atomic stores), so no release fence is needed; the storing wave
-    // drains them, one lane takes a ticket, and the last arriver acquires before reading.
-    {
-        const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const double v = wave_sum(out8[k]);
-            if (lane == 0) red[wave][k] = v;
-        }
-        __syncthreads();
-        if (tid < 8) {
-            double v = 0.0;
-            for (int wv = 0; wv < kKdThreads / 64; ++wv) v += red[wv][tid];
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.main_partial) + (long long)blockIdx.x * 8 + tid,
-                               (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __shared__ int last_flag;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (t == gridDim.x - 1);
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        last_flag = last;
-    }
-    __syncthreads();
-    if (!last_flag) return;
-    kd_finalize(a.main_partial, (int)gridDim.x, a.totals, a.out3, a.T, a.alpha, a.bw, a.conf);
-    if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    kd_publish_and_finalize(a, out8, red);
 }
 
 template <int VEC, bool GRAD, bool EXT, bool STAGE>
@@ -736,6 +754,271 @@ template <bool EXT>
 __global__ __launch_bounds__(kKdThreads) void kdlite_grad_regs_kernel(KdArgs a) {
     kd_main_body<4, true, EXT, false, true>(a);
 }
+
+// ---- the sweep candidate's head: up-sampling + loss + arg-max histogram in ONE pass ---------------
+//
+// A sweep candidate's forward ends in the segmentation head's convolution ([N,C,h,w] fp16 under
+// autocast) followed by a bilinear up-sampling to [N,C,H,W] fp32, which the loss and the arg-max then
+// each read once: 3 x 4*C bytes per pixel written and read back for values that are a function of a
+// tensor sixteen times smaller.  This kernel interpolates the student's logits on the fly instead: a
+// tile's source rows (all classes) are staged in LDS as fp32, every lane interpolates its four pixels
+// class by class with the arithmetic of upsample_bilinear_kernel (same bits), folds them with the
+// teacher's logits into the loss statistics (kd_fold_stats, as the loss kernel), tracks the arg-max
+// (first maximum wins, a NaN is the maximum) and counts (label, arg-max) into the privatised LDS
+// histogram of the confusion-matrix kernels.  HBM traffic: teacher + labels + the small source.
+struct HeadArgs {
+    KdArgs kd;              // kd.s is unused
+    const __half *low;      // [N][C][in_h][in_w]
+    int in_h, in_w;
+    int align_corners;
+    float scale_h, scale_w;
+    int lds_rows;           // source rows a tile can touch (upper bound, sized on the host)
+    int copies, stride;     // layout of the LDS histogram
+    ConfTail tail;
+};
+
+struct HeadLane {
+    int top[4], bot[4];     // LDS word offsets (within a class plane) of the left neighbours, upper and lower row
+    float w0[4], w1[4];
+    float h0, h1;
+};
+
+// One class plane's four interpolated values of a lane.  A staged row carries one more column, a copy of
+// its last one, so the right neighbour is always the next word.
+__device__ __forceinline__ void head_values(const float *plane, const HeadLane &g, float (&v)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a = plane[g.top[e]], b = plane[g.top[e] + 1];
+        const float c = plane[g.bot[e]], d = plane[g.bot[e] + 1];
+        const float t = __builtin_fmaf(g.w0[e], a, g.w1[e] * b);
+        const float u = __builtin_fmaf(g.w0[e], c, g.w1[e] * d);
+        v[e] = __builtin_fmaf(g.h0, t, g.h1 * u);
+    }
+}
+
+template <int U, bool FULL>
+__device__ __forceinline__ void head_fold(PixStats<4> &st, const float *stage, int plane_words, const HeadLane &g,
+                                          const float *__restrict__ t_img, long long HW, int r, int c0, int C,
+                                          const int (&id)[4], float k2, float (&best)[4], int (&arg)[4]) {
+    float sv[U][4], tv[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int cc = FULL ? c0 + u : min(c0 + u, C - 1);
+        load_vec_nt<4>(t_img + (long long)cc * HW + r, tv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int cc = FULL ? c0 + u : min(c0 + u, C - 1);
+        head_values(stage + cc * plane_words, g, sv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!FULL && c0 + u >= C) break;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            arg[e] = !(sv[u][e] <= best[e]) ? c0 + u : arg[e];
+            best[e] = __builtin_elementwise_maximum(best[e], sv[u][e]);   // NaN-propagating
+        }
+    }
+    if (!FULL) {
+#pragma unroll
+        for (int u = 1; u < U; ++u) {
+            const bool gone = c0 + u >= C;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sv[u][e] = gone ? kNegFill : sv[u][e];
+                tv[u][e] = gone ? kNegFill : tv[u][e];
+            }
+        }
+    }
+    kd_fold_stats<4, U, false>(st, sv, tv, c0, id, k2);
+}
+
+// Source rows of one tile: where they lie, and the split of a chunk number (16 bytes = 8 halves of one
+// class's rows) into class, row and chunk of the row.
+struct HeadRows {
+    int y_lo, y_hi;
+    int per_class;          // chunks per class
+    float inv_per_class;
+};
+
+// NCH = 16-byte source chunks a thread stages per tile at most (the host picks 4 or 8 by the stage's size).
+template <int U, int NCH>
+__global__ __launch_bounds__(kKdThreads) void kdlite_head_kernel(HeadArgs h) {
+    extern __shared__ float4 head_lds_raw[];
+    const KdArgs &a = h.kd;
+    const int C = a.C;
+    const int row_words = h.in_w + 1;
+    const int plane_words = h.lds_rows * row_words;
+    float *stage = reinterpret_cast<float *>(head_lds_raw);               // [C][lds_rows][in_w + 1] fp32
+    unsigned *lds_hist = reinterpret_cast<unsigned *>(stage + C * plane_words);
+    __shared__ double red[kKdThreads / 64][8];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < h.copies * h.stride; i += kKdThreads) lds_hist[i] = 0;
+    unsigned *hist = lds_hist + (tid & (h.copies - 1)) * h.stride;
+    const float k2 = a.invT * kLog2e;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int bad = 0;
+    const TileGeom tg = tile_geom<4>(a);
+    const int W = a.W;
+    const int CU = (C / U) * U;
+    const int chunks_per_row = h.in_w >> 3;   // 8 halves = 16 bytes; in_w % 8 == 0 (host)
+    typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+    const float inv_per_row = 1.0f / (float)chunks_per_row;
+    // the source rows under a tile's output rows
+    auto rows_of = [&](int tile) {
+        const int n = tile / tg.tiles_per_img;
+        const int px_first = (tile - n * tg.tiles_per_img) * kKdThreads * 4;
+        const int px_last = min(px_first + kKdThreads * 4, (int)a.HW) - 1;
+        HeadRows rw;
+        rw.y_lo = (int)src_index(h.scale_h, px_first / W, h.align_corners);
+        const int y_last = (int)src_index(h.scale_h, px_last / W, h.align_corners);
+        rw.y_hi = min(min(y_last + 1, h.in_h - 1), rw.y_lo + h.lds_rows - 1);
+        rw.per_class = (rw.y_hi - rw.y_lo + 1) * chunks_per_row;
+        rw.inv_per_class = 1.0f / (float)rw.per_class;
+        return rw;
+    };
+    // A tile's source rows travel through registers: requested while the previous tile is being worked on,
+    // converted and written to LDS when the previous tile's readers are done.
+    f16x8_t pre[NCH];
+    auto request = [&](int tile, const HeadRows &rw) {
+        const int n = tile / tg.tiles_per_img;
+        const __half *src = h.low + ((long long)n * C * h.in_h + rw.y_lo) * h.in_w;
+        const int total = C * rw.per_class;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int i = tid + j * kKdThreads;
+            if (i < total) {
+                // exact while the numbers stay far below 2^22 (the host bounds the stage)
+                const int c = (int)(((float)i + 0.5f) * rw.inv_per_class);
+                const int k = i - c * rw.per_class;   // rows of one class are contiguous in memory
+                pre[j] = *reinterpret_cast<const f16x8_t *>(src + (long long)c * h.in_h * h.in_w + k * 8);
+            }
+        }
+    };
+    auto deposit = [&](const HeadRows &rw) {
+        const int total = C * rw.per_class;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int i = tid + j * kKdThreads;
+            if (i < total) {
+                const int c = (int)(((float)i + 0.5f) * rw.inv_per_class);
+                const int k = i - c * rw.per_class;
+                const int rr = (int)(((float)k + 0.5f) * inv_per_row);
+                const int kc = k - rr * chunks_per_row;
+                float *d = stage + c * plane_words + rr * row_words + kc * 8;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) d[m] = (float)pre[j][m];
+                if (kc == chunks_per_row - 1) d[8] = (float)pre[j][7];
+            }
+        }
+    };
+    HeadRows rows = rows_of((int)blockIdx.x);
+    if ((int)blockIdx.x < tg.n_tiles) request((int)blockIdx.x, rows);
+    for (int tile = blockIdx.x; tile < tg.n_tiles; tile += gridDim.x) {
+        const int n = tile / tg.tiles_per_img;
+        const int q0 = (tile - n * tg.tiles_per_img) * kKdThreads;
+        const int qi = q0 + tid;
+        const int y_lo = rows.y_lo, y_hi = rows.y_hi;
+        __syncthreads();   // whoever still reads the previous tile's rows (and, first time, the cleared histogram)
+        deposit(rows);
+        __syncthreads();
+        if (tile + (int)gridDim.x < tg.n_tiles) {
+            rows = rows_of(tile + (int)gridDim.x);
+            request(tile + (int)gridDim.x, rows);
+        }
+        if (qi >= tg.per_img) continue;
+        const int r = qi * 4;
+        const int oy = r / W;
+        const int ox = r - oy * W;
+        HeadLane g;
+        {
+            const float sy = src_index(h.scale_h, oy, h.align_corners);
+            const int y0 = min((int)sy, y_hi);
+            const int y1 = min(y0 + 1, y_hi);
+            g.h1 = sy - (float)y0;
+            g.h0 = 1.0f - g.h1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sx = src_index(h.scale_w, ox + e, h.align_corners);
+                const int x0 = min((int)sx, h.in_w - 1);
+                g.w1[e] = sx - (float)x0;
+                g.w0[e] = 1.0f - g.w1[e];
+                g.top[e] = (y0 - y_lo) * row_words + x0;
+                g.bot[e] = (y1 - y_lo) * row_words + x0;
+            }
+        }
+        const float *t_img = a.t + (long long)n * C * a.HW;
+        long long lab[4];
+        load_labels<4>(a.labels + (long long)n * a.HW + r, lab);
+        int id[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            id[e] = (lab[e] == a.ignore_index) ? -1 : ((lab[e] >= 0 && lab[e] < C) ? (int)lab[e] : -2);
+
+        PixStats<4> st;
+        float best[4];
+        int arg[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            st.ms[e] = st.mt[e] = kNegFill;
+            st.zs[e] = st.z1[e] = st.zt[e] = st.zt1[e] = st.at[e] = st.sy[e] = 0.f;
+            best[e] = -__builtin_inff();
+            arg[e] = 0;
+        }
+#pragma unroll 1
+        for (int c0 = 0; c0 < CU; c0 += U)
+            head_fold<U, true>(st, stage, plane_words, g, t_img, a.HW, r, c0, C, id, k2, best, arg);
+        if (CU < C) head_fold<U, false>(st, stage, plane_words, g, t_img, a.HW, r, CU, C, id, k2, best, arg);
+
+        if ((best[0] != best[0]) | (best[1] != best[1]) | (best[2] != best[2]) | (best[3] != best[3])) {
+            // a NaN among a pixel's logits: the exact class-by-class walk
+            float bv[4];
+            head_values(stage, g, bv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) arg[e] = 0;
+            for (int c = 1; c < C; ++c) {
+                float v[4];
+                head_values(stage + c * plane_words, g, v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool take = (v[e] > bv[e]) || (v[e] != v[e] && bv[e] == bv[e]);
+                    bv[e] = take ? v[e] : bv[e];
+                    arg[e] = take ? c : arg[e];
+                }
+            }
+        }
+        float p_kl = 0.f, p_nv = 0.f, p_ce = 0.f, p_w = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (lab[e] >= 0 && lab[e] < C) atomicAdd(&hist[(int)lab[e] * C + arg[e]], 1u);
+            if (id[e] == -2) ++bad;
+            const float kl = a.invT * st.at[e] / st.zt[e] - fast_ln(st.zt[e]) + fast_ln(st.zs[e]);
+            const float nll = fast_ln(st.z1[e]) - (st.sy[e] - st.ms[e]);
+            const float wy = (id[e] >= 0) ? (a.class_w ? a.class_w[id[e]] : 1.f) : 0.f;
+            if (id[e] != -1) {
+                p_kl += kl;
+                p_nv += 1.f;
+            }
+            if (id[e] >= 0) {
+                p_ce += wy * nll;
+                p_w += wy;
+            }
+        }
+        acc[0] += p_kl;
+        acc[1] += p_nv;
+        acc[2] += p_ce;
+        acc[3] += p_w;
+    }
+    if (bad) atomicAdd(reinterpret_cast<unsigned long long *>(a.bad), (unsigned long long)bad);
+    conf_finish<kKdThreads>(lds_hist, h.copies, h.stride, C * C, 0u, h.tail);
+    double out8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out8[k] = k < 4 ? acc[k % 4] : 0.0;
+    __syncthreads();
+    kd_publish_and_finalize(a, out8, red);
+}
+
 
 __global__ __launch_bounds__(256) void scale_inplace_kernel(float *x, int64_t n, const float *scale) {
     const float s = *scale;
@@ -919,6 +1202,106 @@ extern "C" int spice_kdlite_forward(const float *student, const float *teacher, 
     }
     return vec4 ? kd_launch<4>(a, grad != nullptr, ext, (int)blocks, st)
                 : kd_launch<1>(a, grad != nullptr, ext, (int)blocks, st);
+}
+
+SPICE_ENV_KNOB(knob_head_blocks_per_cu, "SPICE_HEAD_BLOCKS_PER_CU", 0)   // tuning knobs (host side only)
+
+constexpr size_t kHeadMaxLdsBytes = 64 * 1024;   // two workgroups per compute unit at least
+
+extern "C" int spice_sweep_head_f16(const void *low, const float *teacher, const int64_t *labels, int64_t n,
+                                    int64_t c, int64_t in_h, int64_t in_w, int64_t h, int64_t w,
+                                    int32_t align_corners, float scale_h, float scale_w,
+                                    const spice_kdlite_params *params, float *out3, int64_t *conf,
+                                    void *kd_workspace, size_t kd_workspace_bytes, void *conf_workspace,
+                                    size_t conf_workspace_bytes, void *stream) {
+    if (!params || !out3 || !conf || !kd_workspace || !conf_workspace || !low || !teacher || !labels) return SPICE_ERR_ARG;
+    if (n < 1 || c < 1 || h < 1 || w < 1 || in_h < 1 || in_w < 1) return SPICE_ERR_ARG;
+    if (!(params->temperature > 0.f)) return SPICE_ERR_ARG;
+    if (kd_workspace_bytes < kKdWorkspace) return SPICE_ERR_WORKSPACE;
+    if (!aligned16(kd_workspace) || !aligned16(conf_workspace) || !aligned8(conf)) return SPICE_ERR_ARG;
+    // what this kernel does not cover is left to the three separate launches
+    if (params->boundary_weight > 1.0f || params->confidence_weight != 0) return SPICE_ERR_UNSUPPORTED;
+    if (c > 1024 || c * c > kConfLdsBins || h > INT32_MAX || w > INT32_MAX || in_h > h || in_w > w) return SPICE_ERR_UNSUPPORTED;
+    const int64_t hw = h * w;
+    if (hw > INT32_MAX - 4096 || n > kConfMaxPixels / hw) return SPICE_ERR_UNSUPPORTED;
+    if (w % 4 != 0 || in_w % 8 != 0) return SPICE_ERR_UNSUPPORTED;   // a lane's four pixels lie in one row; 16-byte source chunks
+    if (!aligned16(low) || !aligned16(teacher) || !aligned16(labels)) return SPICE_ERR_UNSUPPORTED;
+    if (conf_workspace_bytes < spice_confusion_workspace_bytes(n * hw, (int32_t)c)) return SPICE_ERR_WORKSPACE;
+
+    HeadArgs ha;
+    ha.low = static_cast<const __half *>(low);
+    ha.in_h = (int)in_h;
+    ha.in_w = (int)in_w;
+    ha.align_corners = align_corners ? 1 : 0;
+    if (ha.align_corners) {   // torch's area_pixel_compute_scale, as spice_upsample_bilinear
+        ha.scale_h = h > 1 ? static_cast<float>(in_h - 1) / static_cast<float>(h - 1) : 0.0f;
+        ha.scale_w = w > 1 ? static_cast<float>(in_w - 1) / static_cast<float>(w - 1) : 0.0f;
+    } else {
+        ha.scale_h = scale_h > 0.0f ? 1.0f / scale_h : static_cast<float>(in_h) / static_cast<float>(h);
+        ha.scale_w = scale_w > 0.0f ? 1.0f / scale_w : static_cast<float>(in_w) / static_cast<float>(w);
+    }
+    if (ha.scale_h > 1.0f || ha.scale_w > 1.0f) return SPICE_ERR_UNSUPPORTED;
+    // output rows a tile of 1024 consecutive pixels can touch, and the source rows under them: the
+    // span of the upper rows, the lower neighbour of the last, one more where the truncations fall
+    const int64_t tile_px = (int64_t)kKdThreads * 4;
+    int64_t out_rows = (tile_px % w == 0) ? tile_px / w : tile_px / w + 2;
+    if (out_rows > h) out_rows = h;
+    int64_t lds_rows = (int64_t)((float)(out_rows - 1) * ha.scale_h + 1e-3f) + 3;
+    if (lds_rows > in_h) lds_rows = in_h;
+    ha.lds_rows = (int)lds_rows;
+    const ConfGeom g = conf_geom((int)c);
+    ha.copies = g.copies;
+    ha.stride = g.stride;
+    const size_t stage_bytes = (size_t)c * lds_rows * (in_w + 1) * sizeof(float);
+    const size_t lds_bytes = stage_bytes + (size_t)g.copies * g.stride * 4;
+    if (lds_bytes > kHeadMaxLdsBytes) return SPICE_ERR_UNSUPPORTED;
+
+    const int64_t tiles = n * ceil_div(hw / 4, kKdThreads);
+    if (tiles > INT32_MAX) return SPICE_ERR_UNSUPPORTED;
+    const long per_cu = knob_head_blocks_per_cu() >= 1 ? knob_head_blocks_per_cu() : 2;
+    int64_t blocks = tiles;
+    if (blocks > per_cu * device_cu_count()) blocks = per_cu * device_cu_count();
+    if (blocks > kConfMaxBlocks) blocks = kConfMaxBlocks;   // also within kKdMaxBlocks
+
+    char *ws = static_cast<char *>(kd_workspace);
+    KdArgs &a = ha.kd;
+    a.s = nullptr;
+    a.t = teacher;
+    a.labels = reinterpret_cast<const long long *>(labels);
+    a.grad = nullptr;
+    a.class_w = params->class_weight;
+    a.upstream = nullptr;
+    a.pre_partial = reinterpret_cast<double *>(ws + kKdOffPre);
+    a.main_partial = reinterpret_cast<double *>(ws + kKdOffMain);
+    a.bad = reinterpret_cast<long long *>(ws + kKdOffBad);
+    a.ticket = reinterpret_cast<unsigned *>(ws + kKdOffTicket);
+    a.totals = reinterpret_cast<double *>(ws + kKdOffTotals);
+    a.out3 = out3;
+    a.N = n;
+    a.HW = hw;
+    a.C = (int)c;
+    a.H = (int)h;
+    a.W = (int)w;
+    a.pre_blocks = (int)blocks;
+    a.ignore_index = params->ignore_index;
+    a.T = params->temperature;
+    a.invT = 1.0f / params->temperature;
+    a.alpha = params->alpha;
+    a.bw = params->boundary_weight;
+    a.coef_ce = params->alpha;
+    a.coef_kd = 1.0f - params->alpha;
+    a.conf = 0;
+    ha.tail = conf_tail(conf_workspace, conf, nullptr, (int)blocks);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t chunks = c * lds_rows * (in_w / 8);   // 16-byte source chunks of a tile
+    if (chunks > 8 * kKdThreads) return SPICE_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)blocks), block(kKdThreads);
+    if (chunks > 4 * kKdThreads)
+        hipLaunchKernelGGL((kdlite_head_kernel<4, 8>), grid, block, lds_bytes, st, ha);
+    else
+        hipLaunchKernelGGL((kdlite_head_kernel<4, 4>), grid, block, lds_bytes, st, ha);
+    SPICE_LAUNCH_CHECK();
+    return SPICE_OK;
 }
 
 extern "C" int spice_scale_inplace(float *x, int64_t n, const float *scale, void *stream) {

@@ -250,6 +250,53 @@ std::tuple<Tensor, Tensor> kdlite_forward(const Tensor &student, const Tensor &t
     return std::make_tuple(out3, grad);
 }
 
+// Up-sampling + loss + arg-max histogram of a sweep candidate in one launch.  Returns out3, or a tensor
+// without elements when the library does not cover the case (nothing was launched; the caller makes the
+// three separate calls).
+Tensor sweep_head(const Tensor &low, const Tensor &teacher, const Tensor &labels, Tensor conf, bool align_corners,
+                  double scale_h, double scale_w, double temperature, double alpha, int64_t ignore_index,
+                  const c10::optional<Tensor> &class_weight, Tensor kd_workspace, Tensor conf_workspace) {
+    check_dev(low, "low_logits", at::kHalf);
+    check_dev(teacher, "teacher_logits", at::kFloat);
+    check_dev(labels, "labels", at::kLong);
+    check_dev(kd_workspace, "kd_workspace", at::kByte);
+    check_dev(conf_workspace, "conf_workspace", at::kByte);
+    check_same_device(low, teacher, "teacher_logits");
+    check_same_device(low, labels, "labels");
+    check_same_device(low, conf, "conf");
+    check_same_device(low, kd_workspace, "kd_workspace");
+    check_same_device(low, conf_workspace, "conf_workspace");
+    TORCH_CHECK_VALUE(low.dim() == 4 && teacher.dim() == 4 && teacher.size(0) == low.size(0) && teacher.size(1) == low.size(1),
+                      "low_logits [N,C,h,w] and teacher_logits [N,C,H,W] must agree in N and C");
+    const int64_t n = low.size(0), c = low.size(1), h = teacher.size(2), w = teacher.size(3);
+    check_conf(conf, c);
+    TORCH_CHECK_VALUE(labels.dim() == 3 && labels.size(0) == n && labels.size(1) == h && labels.size(2) == w,
+                      "labels must be [", n, ",", h, ",", w, "], got ", labels.sizes());
+    spice_kdlite_params p;
+    p.temperature = (float)temperature;
+    p.alpha = (float)alpha;
+    p.boundary_weight = 1.0f;
+    p.confidence_weight = 0;
+    p.ignore_index = ignore_index;
+    p.class_weight = nullptr;
+    if (class_weight.has_value()) {
+        check_dev(*class_weight, "class_weight", at::kFloat);
+        check_same_device(low, *class_weight, "class_weight");
+        TORCH_CHECK_VALUE(class_weight->numel() == c, "class_weight must have C elements");
+        p.class_weight = class_weight->data_ptr<float>();
+    }
+    c10::DeviceGuard guard(low.device());
+    Tensor out3 = at::empty({3}, teacher.options());
+    const int rc = spice_sweep_head_f16(low.data_ptr(), teacher.data_ptr<float>(), labels.data_ptr<int64_t>(), n, c,
+                                        low.size(2), low.size(3), h, w, align_corners ? 1 : 0, (float)scale_h,
+                                        (float)scale_w, &p, out3.data_ptr<float>(), conf.data_ptr<int64_t>(),
+                                        kd_workspace.data_ptr(), (size_t)kd_workspace.numel(), conf_workspace.data_ptr(),
+                                        (size_t)conf_workspace.numel(), current_stream(low));
+    if (rc == SPICE_ERR_UNSUPPORTED) return at::empty({0}, teacher.options());
+    check_rc(rc, "spice_sweep_head_f16");
+    return out3;
+}
+
 void scale_inplace(Tensor x, const Tensor &scale) {
     check_dev(x, "x", at::kFloat);
     check_dev(scale, "scale", at::kFloat);
@@ -635,6 +682,9 @@ TORCH_LIBRARY(spice, m) {
           &confusion_update);
     m.def("confusion_update_static(Tensor(a!) conf, Tensor preds, Tensor target, int num_classes, "
           "Tensor(b!)? invalid_count) -> ()", &confusion_update_static);
+    m.def("sweep_head(Tensor low, Tensor teacher, Tensor labels, Tensor(a!) conf, bool align_corners, float scale_h, "
+          "float scale_w, float temperature, float alpha, int ignore_index, Tensor? class_weight, "
+          "Tensor(b!) kd_workspace, Tensor(c!) conf_workspace) -> Tensor", &sweep_head);
     m.def("argmax_confusion_update(Tensor(a!) conf, Tensor logits, Tensor target, int num_classes, "
           "Tensor(b!) workspace) -> ()", &argmax_confusion_update);
     m.def("kdlite_forward(Tensor student, Tensor teacher, Tensor labels, float temperature, float alpha, "

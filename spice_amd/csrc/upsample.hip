@@ -11,6 +11,7 @@
 // index = scale * dst or scale * (dst + 0.5) - 0.5 clamped at 0, lambdas from the truncated index,
 // the two-level weighted sum with the same fused multiply-adds), all in fp32.
 #include "common.h"
+#include "bilinear_math.h"
 
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
@@ -36,12 +37,6 @@ struct UpArgs {
     int planes_per_group;        // destination: planes of a group lie one behind the other,
     int64_t dst_group_stride;    // groups this many elements apart (a channel slice of a larger tensor)
 };
-
-__device__ __forceinline__ float src_index(float scale, int dst, int align_corners) {
-    if (align_corners) return scale * static_cast<float>(dst);
-    const float s = __builtin_fmaf(scale, static_cast<float>(dst) + 0.5f, -0.5f);
-    return s < 0.0f ? 0.0f : s;
-}
 
 template <typename T>
 __device__ __forceinline__ float to_f32(T v);

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import contextlib
 import copy
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -82,6 +83,10 @@ class SensitivitySweep:
         self.jobs: Dict[int, SliceJob] = {}
         # when set to a list, evaluate() appends a (start, end) HIP event pair around each KD-Lite launch
         self.kd_events: Optional[list] = None
+        #: the candidate's up-sampling, loss and arg-max histogram in one launch where the network's head allows
+        #: it (SPICE_SWEEP_FUSED_HEAD=0: always the three separate launches)
+        self.fused_head = os.environ.get("SPICE_SWEEP_FUSED_HEAD", "1") != "0"
+        self.head_launches = 0
         self._geometry, self._geometry_for, self._warmed, self._fresh_logits = {}, None, set(), None
 
     # -- cost of a candidate, for balancing ranks ---------------------------------------------
@@ -351,6 +356,7 @@ class SensitivitySweep:
         the candidate belongs to (measurements that want one candidate on the device at a time)."""
         lane = self if first_lane else self._lane_of(index)
         if lane is not self:
+            lane.fused_head = self.fused_head
             with torch.cuda.stream(lane._stream):
                 return lane._evaluate(index, images, labels, teacher_logits, conf_out, kd_out, self.kd_events)
         return self._evaluate(index, images, labels, teacher_logits, conf_out, kd_out, self.kd_events)
@@ -362,21 +368,63 @@ class SensitivitySweep:
         job = self.jobs[index]
         moved = job.run(keep_undo=True)
         try:
-            logits = self.forward(images).contiguous()
-            ops.argmax_confusion_update(conf_out, logits, labels, self.num_classes)
-            if teacher_logits is not None and kd_out is not None:
-                student = logits.float()
-                if kd_events is not None:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with_kd = teacher_logits is not None and kd_out is not None
+            e0 = e1 = None
+            if with_kd and kd_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            parts = self._forward_to_head(images) if (with_kd and self.fused_head) else None
+            logits = None
+            if parts is not None:
+                # up-sampling, loss and arg-max histogram in one launch over the head's small fp16 output
+                low, up = parts
+                if e0 is not None:
                     e0.record()
-                out3, _, _ = ops.kdlite_forward(student, teacher_logits, labels, **self.kd)
-                if kd_events is not None:
-                    e1.record()
-                    kd_events.append((e0, e1))
-                kd_out.copy_(out3)
+                out3 = ops.sweep_head(low, teacher_logits, labels, conf_out, align_corners=True,
+                                      scale_factor=float(up.scale_factor), **self.kd)
+                if out3 is None:   # a shape the one-launch kernel does not cover
+                    with torch.no_grad(), torch.autocast("cuda", dtype=self.autocast_dtype):
+                        logits = up(low).contiguous()
+                else:
+                    if e1 is not None:
+                        e1.record()
+                        kd_events.append((e0, e1))
+                    kd_out.copy_(out3)
+                    self.head_launches += 1
+            else:
+                logits = self.forward(images).contiguous()
+            if logits is not None:
+                ops.argmax_confusion_update(conf_out, logits, labels, self.num_classes)
+                if with_kd:
+                    student = logits.float()
+                    if e0 is not None:
+                        e0.record()
+                    out3, _, _ = ops.kdlite_forward(student, teacher_logits, labels, **self.kd)
+                    if e1 is not None:
+                        e1.record()
+                        kd_events.append((e0, e1))
+                    kd_out.copy_(out3)
         finally:
             job.undo()
         return moved
+
+    def _forward_to_head(self, images: torch.Tensor):
+        """(the head convolution's fp16 output, the up-sampling module behind it) when the network ends in
+        convolution -> nn.UpsamplingBilinear2d -> identity and runs under fp16 autocast on the library's kernels;
+        None otherwise (the caller then runs the whole forward)."""
+        from .nets import layers
+        from .nets.decoders import BilinearUp
+        m = self.model
+        head = getattr(m, "segmentation_head", None)
+        if (self.autocast_dtype != torch.float16 or not images.is_cuda or not layers.library_forward()
+                or not isinstance(head, nn.Sequential) or len(head) != 3 or not isinstance(head[1], BilinearUp)
+                or type(head[2]) is not nn.Identity or not hasattr(m, "encoder") or not hasattr(m, "decoder")
+                or type(m).forward is not _segmentation_forward()):
+            return None
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            low = head[0](m.decoder(m.encoder(self._network_input(images))))
+        if low.dtype != torch.float16 or low.dim() != 4:
+            return None
+        return low.contiguous(), head[1]
 
     def run(self, images: torch.Tensor, labels: torch.Tensor, indices: Optional[Sequence[int]] = None,
             with_kd: bool = True) -> Dict[str, torch.Tensor]:
@@ -432,6 +480,11 @@ class SensitivitySweep:
             for tb in ([table, kd] if with_kd else [table]):
                 sdist.all_reduce_sum_(tb)
         return {"confusion": table, "kd": kd, "miou": miou_from_confusion(table)}
+
+
+def _segmentation_forward():
+    from .nets.decoders import SegmentationModel
+    return SegmentationModel.forward
 
 
 def miou_from_confusion(table: torch.Tensor) -> torch.Tensor:

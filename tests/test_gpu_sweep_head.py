@@ -1,0 +1,166 @@
+"""The sweep candidate's tail in one launch (spice_sweep_head_f16): up-sampling + KD-Lite loss +
+arg-max histogram.  Checked against the three separate launches it replaces (interpolated logits
+bit for bit, so the confusion matrix is identical; the loss differs only by the order in which
+workgroups' fp64 partial sums are added) and against the CPU oracle (torch's interpolation in
+fp32, first-maximum arg-max, histogram, fp64 loss)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import confusion as oc
+from oracle import kdlite as ok
+from oracle import upsample as ou
+from spice_amd import _native as nat
+from spice_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5  # tolerance of the north-star statement for the fp32 KD loss
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    nat.lib()
+    return torch.device("cuda:0")
+
+
+def _inputs(seed, n, c, h, w, scale, ignore_share=0.1):
+    g = np.random.default_rng(seed)
+    low = (g.standard_normal((n, c, h, w)) * 3).astype(np.float16)
+    teacher = (g.standard_normal((n, c, h * scale, w * scale)) * 3).astype(np.float32)
+    lab = synth.label_map(seed, n, h * scale, w * scale, c, "uniform")
+    lab[g.random(lab.shape) < ignore_share] = 255
+    return low, teacher, lab
+
+
+def _three_launches(dev, low, teacher, lab, c, scale, align, kw):
+    up = ops.upsample_bilinear(low, scale_factor=float(scale), align_corners=align, out_dtype=torch.float32)
+    conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
+    ops.argmax_confusion_update(conf, up, lab, c)
+    out3, _, _ = ops.kdlite_forward(up, teacher, lab, **kw)
+    return conf, out3, up
+
+
+CASES = [
+    # n, c, h, w (source), scale, align_corners
+    (8, 21, 128, 128, 4, True),     # the bench's shape: [8,21,512,512]
+    (2, 21, 32, 32, 4, True),
+    (2, 5, 24, 40, 4, False),       # W = 160: tiles straddle rows; class count below one step
+    (1, 19, 16, 8, 2, True),        # x2, W = 16
+    (3, 3, 8, 16, 8, False),
+    (1, 6, 40, 24, 4, True),        # W = 96 does not divide a tile
+    (2, 9, 16, 264, 4, True),       # long rows: W = 1056 > one tile
+]
+
+
+@pytest.mark.parametrize("n,c,h,w,scale,align", CASES)
+def test_sweep_head_equals_three_launches(dev, n, c, h, w, scale, align):
+    low, teacher, lab = _inputs(11, n, c, h, w, scale)
+    kw = dict(temperature=4.0, alpha=0.7)
+    low_d, t_d, lab_d = torch.from_numpy(low).to(dev), torch.from_numpy(teacher).to(dev), torch.from_numpy(lab).to(dev)
+    ref_conf, ref_out3, _ = _three_launches(dev, low_d, t_d, lab_d, c, scale, align, kw)
+    conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
+    for rep in (1, 2):   # the second call finds the tickets returned to zero and adds to the same matrix
+        out3 = ops.sweep_head(low_d, t_d, lab_d, conf, align_corners=align, scale_factor=float(scale), **kw)
+        assert out3 is not None, "the library must cover this shape"
+        np.testing.assert_array_equal(conf.cpu().numpy(), rep * ref_conf.cpu().numpy())
+        np.testing.assert_allclose(out3.cpu().numpy(), ref_out3.cpu().numpy(), rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("n,c,h,w,scale,align", [(2, 21, 32, 32, 4, True), (2, 5, 24, 40, 4, False),
+                                                  (1, 19, 16, 8, 2, True)])
+def test_sweep_head_vs_oracle(dev, n, c, h, w, scale, align):
+    low, teacher, lab = _inputs(5, n, c, h, w, scale)
+    weights = torch.tensor(ok.FIVE_CLASS_WEIGHTS, dtype=torch.float32) if c == 5 else None
+    up = ou.upsample_bilinear(torch.from_numpy(low), scale_factor=float(scale), align_corners=align).numpy()
+    ref_conf = np.zeros((c, c), dtype=np.int64)
+    oc.update_confusion(ref_conf, oc.argmax_first(up), lab, c)
+    ref = ok.kdlite_loss_f64(up, teacher, lab, temperature=4.0, alpha=0.7, num_classes=c)
+    conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
+    out3 = ops.sweep_head(torch.from_numpy(low).to(dev), torch.from_numpy(teacher).to(dev), torch.from_numpy(lab).to(dev),
+                          conf, align_corners=align, scale_factor=float(scale), temperature=4.0, alpha=0.7,
+                          class_weight=None if weights is None else weights.to(dev))
+    assert out3 is not None
+    got = out3.cpu().numpy().astype(np.float64)
+    if weights is None:
+        want = np.array([ref["total"], ref["ce"], ref["kd"]])
+        np.testing.assert_allclose(got, want, rtol=REL)
+    # torch's CPU interpolation and the device kernel agree to the last bit on almost every value; an arg-max
+    # can only differ where two interpolated logits are within one rounding of each other
+    diff = np.abs(conf.cpu().numpy() - ref_conf).sum()
+    assert diff <= 2 * max(1, int(1e-5 * lab.size)), diff
+
+
+def test_sweep_head_ties_nan_and_infinities(dev):
+    """First maximum wins on exact ties; a NaN is the maximum (first NaN wins); rows of -inf pick class 0;
+    out-of-range labels are skipped by the histogram and counted by the loss."""
+    n, c, h, w, scale = 2, 21, 16, 16, 4
+    g = np.random.default_rng(3)
+    low = (np.round(g.standard_normal((n, c, h, w)) * 2) / 2).astype(np.float16)   # many exact ties
+    low[0, :, 3:6, 2:9] = 1.0                                                      # whole rows of ties -> class 0
+    low[1, 7, 5, 5] = np.nan
+    low[1, 12, 5, 5] = np.nan
+    low[1, :, 10, 10] = -np.inf
+    low[0, 4, 12, 3] = np.inf
+    teacher = (g.standard_normal((n, c, h * scale, w * scale)) * 2).astype(np.float32)
+    lab = synth.label_map(3, n, h * scale, w * scale, c, "uniform")
+    lab[0, :4, :] = 255
+    lab[1, 5, :7] = -3
+    lab[1, 6, :7] = c + 2
+    kw = dict(temperature=2.0, alpha=0.5)
+    low_d, t_d, lab_d = torch.from_numpy(low).to(dev), torch.from_numpy(teacher).to(dev), torch.from_numpy(lab).to(dev)
+    ref_conf, ref_out3, up = _three_launches(dev, low_d, t_d, lab_d, c, scale, True, kw)
+    # the separate launches themselves against torch's arg-max on the same interpolated logits
+    pred = up.argmax(1)
+    want = np.zeros((c, c), dtype=np.int64)
+    oc.update_confusion(want, pred.cpu().numpy(), lab, c)
+    np.testing.assert_array_equal(ref_conf.cpu().numpy(), want)
+    before = ops.kdlite_bad_label_count(dev)
+    conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
+    out3 = ops.sweep_head(low_d, t_d, lab_d, conf, align_corners=True, scale_factor=float(scale), **kw)
+    assert out3 is not None
+    np.testing.assert_array_equal(conf.cpu().numpy(), want)
+    a, b = out3.cpu().numpy(), ref_out3.cpu().numpy()
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    np.testing.assert_allclose(a[~np.isnan(a)], b[~np.isnan(b)], rtol=1e-6)
+    assert ops.kdlite_bad_label_count(dev) - before == 14
+
+
+def test_sweep_head_declines_what_it_does_not_cover(dev):
+    c = 4
+    t = torch.zeros(1, c, 12, 12, device=dev)
+    lab = torch.zeros(1, 12, 12, dtype=torch.int64, device=dev)
+    conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
+    low = torch.zeros(1, c, 3, 3, dtype=torch.float16, device=dev)   # in_w % 8 != 0
+    assert ops.sweep_head(low, t, lab, conf, scale_factor=4.0, temperature=4.0, alpha=0.5) is None
+    assert int(conf.sum()) == 0
+    with pytest.raises((TypeError, RuntimeError)):
+        ops.sweep_head(low.float(), t, lab, conf, scale_factor=4.0, temperature=4.0, alpha=0.5)
+    with pytest.raises((ValueError, RuntimeError)):
+        ops.sweep_head(low, t, lab[:, :5], conf, scale_factor=4.0, temperature=4.0, alpha=0.5)
+
+
+def test_sweep_uses_the_head_launch_and_gives_the_same_tables(dev):
+    """SensitivitySweep with the one-launch head against the same sweep on the three separate launches:
+    identical confusion matrices, losses to 1e-6."""
+    import torch.nn as nn
+    from spice_amd import nets
+    from spice_amd.sweep import SensitivitySweep
+    torch.manual_seed(0)
+    model = nets.create_model("DeepLabV3Plus", "resnet50", 21).to(dev).eval()
+    ignored = [m for m in model.segmentation_head.modules() if isinstance(m, nn.Conv2d)]
+    sweep = SensitivitySweep(model, 21, ratios=(0.3,), ignored_layers=ignored)
+    images = torch.randn(2, 3, 128, 128, device=dev)
+    labels = torch.from_numpy(synth.label_map(1, 2, 128, 128, 21, "blocky")).to(dev)
+    idx = list(range(0, len(sweep.candidates), max(1, len(sweep.candidates) // 5)))[:5]
+    sweep.fused_head = True
+    got = sweep.run(images, labels, indices=idx)
+    assert sweep.head_launches == len(idx)
+    sweep.fused_head = False
+    ref = sweep.run(images, labels, indices=idx)
+    assert sweep.head_launches == len(idx)
+    np.testing.assert_array_equal(got["confusion"].cpu().numpy(), ref["confusion"].cpu().numpy())
+    # the un-pruned network is the teacher: the KL term is ~1e-6, fp32 noise around it
+    np.testing.assert_allclose(got["kd"].cpu().numpy(), ref["kd"].cpu().numpy(), rtol=1e-5, atol=1e-7)
+    assert int(got["confusion"][idx[0]].sum()) == int((labels != 255).sum())

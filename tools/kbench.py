@@ -186,6 +186,28 @@ def main():
             fns = [lambda a=a: ops.argmax_confusion_update(conf, a, lab, c) for a in sets]
             report(f"argmax_confusion_{str(dt)[6:]}", timed(fns, args.iters), n * h * w * (c * sz + 8))
 
+    if want("head"):
+        # a sweep candidate's tail at the benchmark geometry: head output [8,21,128,128] fp16, teacher logits and
+        # labels at 512x512; one launch against the three it replaces (up-sampling, arg-max histogram, loss)
+        n, c, h, w = 8, 21, 512, 512
+        _, t = synth.logits_pair(77, n, c, h, w)
+        lab = torch.from_numpy(synth.label_map(77, n, h, w, c)).to(dev)
+        teachers = [torch.from_numpy(t).to(dev) + k for k in range(3)]
+        lows = [torch.randn(n, c, h // 4, w // 4, device=dev).half() for _ in range(3)]
+        conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
+        nbytes = n * c * (h // 4) * (w // 4) * 2 + n * h * w * (c * 4 + 8)
+        fns = [lambda a=a, b=b: ops.sweep_head(a, b, lab, conf, align_corners=True, scale_factor=4.0, temperature=4.0,
+                                               alpha=0.7) for a, b in zip(lows, teachers)]
+        report("sweep_head (up-sampling + loss + arg-max histogram, one launch)", timed(fns, args.iters), nbytes)
+
+        def three(a, b):
+            up = ops.upsample_bilinear(a, scale_factor=4.0, align_corners=True, out_dtype=torch.float32)
+            ops.argmax_confusion_update(conf, up, lab, c)
+            ops.kdlite_forward(up, b, lab, temperature=4.0, alpha=0.7)
+        fns = [lambda a=a, b=b: three(a, b) for a, b in zip(lows, teachers)]
+        report("the same in three launches (up-sampling, arg-max histogram, loss)", timed(fns, args.iters), nbytes)
+        del teachers, lows
+
     if want("upsample"):
         # the two x4 steps of DeepLabV3+ at the benchmark geometry: head [8,21,128,128] fp16 -> fp32 logits,
         # decoder [8,256,32,32] fp16 -> fp16; torch's own kernel beside them

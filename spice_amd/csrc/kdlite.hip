@@ -844,7 +844,7 @@ struct HeadRows {
 
 // NCH = 16-byte source chunks a thread stages per tile at most (the host picks 4 or 8 by the stage's size).
 template <int U, int NCH>
-__global__ __launch_bounds__(kKdThreads) void kdlite_head_kernel(HeadArgs h) {
+__global__ __launch_bounds__(kKdThreads, 2) void kdlite_head_kernel(HeadArgs h) {   // two waves per SIMD at least
     extern __shared__ float4 head_lds_raw[];
     const KdArgs &a = h.kd;
     const int C = a.C;
@@ -969,7 +969,12 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_head_kernel(HeadArgs h) {
 #pragma unroll 1
         for (int c0 = 0; c0 < CU; c0 += U)
             head_fold<U, true>(st, stage, plane_words, g, t_img, a.HW, r, c0, C, id, k2, best, arg);
-        if (CU < C) head_fold<U, false>(st, stage, plane_words, g, t_img, a.HW, r, CU, C, id, k2, best, arg);
+        // what is left of the class axis: a single plane as a step of its own (21 classes = 5 x 4 + 1), more as one
+        // step whose surplus planes are filled
+        if (C - CU == 1)
+            head_fold<1, true>(st, stage, plane_words, g, t_img, a.HW, r, CU, C, id, k2, best, arg);
+        else if (CU < C)
+            head_fold<U, false>(st, stage, plane_words, g, t_img, a.HW, r, CU, C, id, k2, best, arg);
 
         if ((best[0] != best[0]) | (best[1] != best[1]) | (best[2] != best[2]) | (best[3] != best[3])) {
             // a NaN among a pixel's logits: the exact class-by-class walk

@@ -1,5 +1,5 @@
-"""Per-step GPU time of the sweep from a rocprofv3 kernel trace of bench.py: finds the timed run of
-KD-Lite launches and sums kernel durations between them.  Usage: stepbreakdown.py <kernel_trace.csv> [steps]"""
+"""Per-step GPU time of the sweep from a rocprofv3 kernel trace of bench.py: finds a run of
+candidate-ending launches and sums kernel durations between them.  Usage: stepbreakdown.py <kernel_trace.csv> [steps]"""
 import collections
 import csv
 import sys
@@ -7,7 +7,11 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-kd = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("void spice::kdlite_main_kernel<4, false, false, false>")]
+# a candidate ends in one launch of the head kernel (up-sampling + loss + arg-max histogram), or, on the three-launch
+# route, of the plain loss kernel
+kd = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("void spice::kdlite_head_kernel")]
+if len(kd) <= steps:
+    kd = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("void spice::kdlite_main_kernel<4, false, false, false>")]
 ts = [int(rows[i]["Start_Timestamp"]) for i in kd]
 gaps = [(ts[k + 1] - ts[k]) / 1e6 for k in range(len(ts) - 1)]
 best, s = (0, 0), None

@@ -521,13 +521,18 @@ def main():
     # the head's small fp16 output, the teacher's logits and the labels), or the loss kernel alone on full-size logits
     one_launch_head = any(l.head_launches for l in sweep._lanes)
     if one_launch_head:
-        kd_bytes = BATCH * CLASSES * (SIZE // 4) * (SIZE // 4) * 2 + BATCH * SIZE * SIZE * (CLASSES * 4 + 8)
-        kd_kernel = ("spice::kdlite_head_kernel<4,4> (one launch per candidate: bilinear up-sampling of the head's fp16 "
-                     "logits + KD-Lite loss + arg-max + confusion histogram; replaces upsample_bilinear_kernel, "
-                     "argmax_confusion_kernel and kdlite_main_kernel = 128 us and 550 MB of traffic per candidate)")
-        kd_key = "spice::kdlite_head_kernel<4, 4>"
-        kd_note = ("bound by vector arithmetic, not by memory: three exponentials (quarter rate) and the six-operation "
-                   "interpolation per logit; the loss kernel alone on full-size logits reaches 0.71 (`kernels` table)")
+        prepared = sweep._teacher_prepared is not None   # teacher's softmax taken once per sweep: + 4 bytes per pixel
+        kd_bytes = (BATCH * CLASSES * (SIZE // 4) * (SIZE // 4) * 2 + BATCH * SIZE * SIZE * (CLASSES * 4 + 8)
+                    + (BATCH * SIZE * SIZE * 4 if prepared else 0))
+        kd_kernel = (f"spice::kdlite_head_kernel<4,4,{str(prepared).lower()}> (one launch per candidate: bilinear "
+                     "up-sampling of the head's fp16 logits + KD-Lite loss + arg-max + confusion histogram"
+                     + (", against the teacher's probabilities prepared once per sweep" if prepared else "") +
+                     "; replaces upsample_bilinear_kernel, argmax_confusion_kernel and kdlite_main_kernel = 128 us "
+                     "and 550 MB of traffic per candidate)")
+        kd_key = f"spice::kdlite_head_kernel<4, 4, {str(prepared).lower()}>"
+        kd_note = ("bound by vector arithmetic, not by memory: " + ("two" if prepared else "three") + " exponentials "
+                   "(quarter rate) and the six-operation interpolation per logit; the loss kernel alone on full-size "
+                   "logits reaches 0.71 (`kernels` table)")
     else:
         kd_bytes = BATCH * SIZE * SIZE * (2 * CLASSES * 4 + 8)
         kd_kernel = "spice::kdlite_main_kernel<4,false,false,false> (one launch per spice_kdlite_forward call)"

@@ -167,6 +167,13 @@ int spice_kdlite_forward(const float *student, const float *teacher, const int64
                          float coef_ce, float coef_kd, const float *upstream,
                          void *workspace, size_t workspace_bytes, void *stream);
 
+/* Once per teacher of a sensitivity sweep: probs [N,C,H,W] fp32 = softmax(teacher / temperature) over C
+ * and hneg [N,H,W] fp32 = sum_c probs ln probs, the teacher-only parts of PixelKDLoss
+ * (pruning/losses.py:40-58), for spice_sweep_head_f16.  SPICE_ERR_UNSUPPORTED when H*W % 4 != 0 or a
+ * pointer is off 16 bytes. */
+int spice_kd_teacher_prepare(const float *teacher, int64_t n, int64_t c, int64_t h, int64_t w,
+                             float temperature, float *probs, float *hneg, void *stream);
+
 /* The tail of a sensitivity-sweep candidate in ONE launch: the segmentation head's bilinear
  * up-sampling (`nn.UpsamplingBilinear2d` at the end of the models of pruning/models.py:35-39), the
  * KD-Lite loss of the up-sampled logits against the teacher's (pruning/losses.py:127-162) and the
@@ -177,11 +184,15 @@ int spice_kdlite_forward(const float *student, const float *teacher, const int64
  * teacher [N,C,H,W] fp32, labels [N,H,W] int64, out3 3 floats, conf [C,C] int64 (+=).  The two
  * workspaces are those of spice_kdlite_forward and spice_confusion_update (same sizes, same
  * rules).  align_corners / scale_h / scale_w as spice_upsample_bilinear.
+ * teacher_hneg: NULL, or the second output of spice_kd_teacher_prepare for this teacher and
+ * temperature; `teacher` must then be its first output (the probabilities) instead of the logits.
+ * A sweep evaluates every candidate against the same teacher, so the teacher's softmax is taken once
+ * and the per-candidate pass does one exponential per logit less; same loss within fp32 rounding.
  * SPICE_ERR_UNSUPPORTED (nothing launched; use the three separate calls) for the boundary and
  * confidence options, W % 4 != 0, in_w % 8 != 0, pointers off 16 bytes, or source rows too long
  * for the LDS stage. */
-int spice_sweep_head_f16(const void *low, const float *teacher, const int64_t *labels, int64_t n,
-                         int64_t c, int64_t in_h, int64_t in_w, int64_t h, int64_t w,
+int spice_sweep_head_f16(const void *low, const float *teacher, const float *teacher_hneg,
+                         const int64_t *labels, int64_t n, int64_t c, int64_t in_h, int64_t in_w, int64_t h, int64_t w,
                          int32_t align_corners, float scale_h, float scale_w,
                          const spice_kdlite_params *params, float *out3, int64_t *conf,
                          void *kd_workspace, size_t kd_workspace_bytes, void *conf_workspace,

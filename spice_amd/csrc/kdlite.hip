@@ -755,6 +755,55 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_grad_regs_kernel(KdArgs a) 
     kd_main_body<4, true, EXT, false, true>(a);
 }
 
+// Once per teacher (a sweep evaluates hundreds of candidates against the same un-pruned network): the
+// temperature-softmax probabilities p_c = softmax(t / T)_c, [N,C,H,W] fp32, and per pixel sum_c p_c ln p_c.  One lane
+// per four pixels; the class axis is walked three times (maximum, sums, probabilities), the repeats served by L2.
+__global__ __launch_bounds__(256) void kd_teacher_prepare_kernel(const float *__restrict__ t, float *__restrict__ probs,
+                                                                 float *__restrict__ hneg, long long N, long long HW,
+                                                                 int C, float invT) {
+    const float k2 = invT * kLog2e;
+    const long long per_img = HW / 4;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < N * per_img; q += (long long)gridDim.x * 256) {
+        const long long n = q / per_img;
+        const long long r = (q - n * per_img) * 4;
+        const float *tp = t + n * C * HW + r;
+        float m[4] = {kNegFill, kNegFill, kNegFill, kNegFill};
+        for (int c = 0; c < C; ++c) {
+            float v[4];
+            load_vec<4>(tp + (long long)c * HW, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+        }
+        float z[4] = {0.f, 0.f, 0.f, 0.f}, a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < C; ++c) {
+            float v[4];
+            load_vec<4>(tp + (long long)c * HW, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float tc = v[e] - m[e];
+                const float et = fast_exp2(tc * k2);
+                z[e] += et;
+                a[e] = __builtin_fmaf(et, tc, a[e]);
+            }
+        }
+        float iz[4], hn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            iz[e] = 1.0f / z[e];
+            hn[e] = invT * a[e] * iz[e] - fast_ln(z[e]);   // sum p ln p = (1/T) sum p (t - max) - ln Z
+        }
+        store_vec<4>(hneg + n * HW + r, hn);
+        float *pp = probs + n * C * HW + r;
+        for (int c = 0; c < C; ++c) {
+            float v[4], p[4];
+            load_vec<4>(tp + (long long)c * HW, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[e] = fast_exp2((v[e] - m[e]) * k2) * iz[e];
+            store_vec<4>(pp + (long long)c * HW, p);
+        }
+    }
+}
+
 // ---- the sweep candidate's head: up-sampling + loss + arg-max histogram in ONE pass ---------------
 //
 // A sweep candidate's forward ends in the segmentation head's convolution ([N,C,h,w] fp16 under
@@ -767,7 +816,8 @@ __global__ __launch_bounds__(kKdThreads) void kdlite_grad_regs_kernel(KdArgs a) 
 // (first maximum wins, a NaN is the maximum) and counts (label, arg-max) into the privatised LDS
 // histogram of the confusion-matrix kernels.  HBM traffic: teacher + labels + the small source.
 struct HeadArgs {
-    KdArgs kd;              // kd.s is unused
+    KdArgs kd;              // kd.s is unused; kd.t holds the teacher's logits, or (PROBS) its prepared probabilities
+    const float *hneg;      // PROBS: [N][H][W] sum_c p_c ln p_c of the teacher at the temperature
     const __half *low;      // [N][C][in_h][in_w]
     int in_h, in_w;
     int align_corners;
@@ -796,7 +846,37 @@ __device__ __forceinline__ void head_values(const float *plane, const HeadLane &
     }
 }
 
-template <int U, bool FULL>
+// The student's half of kd_fold_stats for a teacher whose temperature-softmax probabilities are given (pv):
+// running maximum, Zs, Z1, the label's logit, and sum_c p_c s_c (in st.at; the teacher's own statistics are not
+// needed: KL = sum p ln p - (1/T) (sum p s - max s) + ln Zs).
+template <int U>
+__device__ __forceinline__ void kd_fold_student(PixStats<4> &st, const float (&sv)[U][4], const float (&pv)[U][4],
+                                                int c0, const int (&id)[4], float k2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float msn = fmaxf(fmaxf(st.ms[e], fmaxf(sv[0][e], sv[1 % U][e])), fmaxf(sv[2 % U][e], sv[3 % U][e]));
+        const float ds = st.ms[e] - msn;  // <= 0
+        float Zs = st.zs[e] * fast_exp2(ds * k2);
+        float Z1 = st.z1[e] * fast_exp2(ds * kLog2e);
+        float ps = st.at[e];
+        float sy = st.sy[e];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float sc = sv[u][e] - msn;
+            Zs += fast_exp2(sc * k2);
+            Z1 += fast_exp2(sc * kLog2e);
+            ps = __builtin_fmaf(pv[u][e], sv[u][e], ps);
+            sy = (c0 + u == id[e]) ? sv[u][e] : sy;
+        }
+        st.ms[e] = msn;
+        st.zs[e] = Zs;
+        st.z1[e] = Z1;
+        st.at[e] = ps;
+        st.sy[e] = sy;
+    }
+}
+
+template <int U, bool FULL, bool PROBS>
 __device__ __forceinline__ void head_fold(PixStats<4> &st, const float *stage, int plane_words, const HeadLane &g,
                                           const float *__restrict__ t_img, long long HW, int r, int c0, int C,
                                           const int (&id)[4], float k2, float (&best)[4], int (&arg)[4]) {
@@ -827,11 +907,14 @@ __device__ __forceinline__ void head_fold(PixStats<4> &st, const float *stage, i
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 sv[u][e] = gone ? kNegFill : sv[u][e];
-                tv[u][e] = gone ? kNegFill : tv[u][e];
+                tv[u][e] = gone ? (PROBS ? 0.0f : kNegFill) : tv[u][e];
             }
         }
     }
-    kd_fold_stats<4, U, false>(st, sv, tv, c0, id, k2);
+    if constexpr (PROBS)
+        kd_fold_student<U>(st, sv, tv, c0, id, k2);
+    else
+        kd_fold_stats<4, U, false>(st, sv, tv, c0, id, k2);
 }
 
 // Source rows of one tile: where they lie, and the split of a chunk number (16 bytes = 8 halves of one
@@ -843,7 +926,8 @@ struct HeadRows {
 };
 
 // NCH = 16-byte source chunks a thread stages per tile at most (the host picks 4 or 8 by the stage's size).
-template <int U, int NCH>
+// PROBS: the teacher comes as prepared probabilities and per-pixel entropy term (kd_teacher_prepare_kernel).
+template <int U, int NCH, bool PROBS>
 __global__ __launch_bounds__(kKdThreads, 2) void kdlite_head_kernel(HeadArgs h) {   // two waves per SIMD at least
     extern __shared__ float4 head_lds_raw[];
     const KdArgs &a = h.kd;
@@ -951,6 +1035,8 @@ __global__ __launch_bounds__(kKdThreads, 2) void kdlite_head_kernel(HeadArgs h) 
         const float *t_img = a.t + (long long)n * C * a.HW;
         long long lab[4];
         load_labels<4>(a.labels + (long long)n * a.HW + r, lab);
+        float hn[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (PROBS) load_vec_nt<4>(h.hneg + (long long)n * a.HW + r, hn);
         int id[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -968,13 +1054,13 @@ __global__ __launch_bounds__(kKdThreads, 2) void kdlite_head_kernel(HeadArgs h) 
         }
 #pragma unroll 1
         for (int c0 = 0; c0 < CU; c0 += U)
-            head_fold<U, true>(st, stage, plane_words, g, t_img, a.HW, r, c0, C, id, k2, best, arg);
+            head_fold<U, true, PROBS>(st, stage, plane_words, g, t_img, a.HW, r, c0, C, id, k2, best, arg);
         // what is left of the class axis: a single plane as a step of its own (21 classes = 5 x 4 + 1), more as one
         // step whose surplus planes are filled
         if (C - CU == 1)
-            head_fold<1, true>(st, stage, plane_words, g, t_img, a.HW, r, CU, C, id, k2, best, arg);
+            head_fold<1, true, PROBS>(st, stage, plane_words, g, t_img, a.HW, r, CU, C, id, k2, best, arg);
         else if (CU < C)
-            head_fold<U, false>(st, stage, plane_words, g, t_img, a.HW, r, CU, C, id, k2, best, arg);
+            head_fold<U, false, PROBS>(st, stage, plane_words, g, t_img, a.HW, r, CU, C, id, k2, best, arg);
 
         if ((best[0] != best[0]) | (best[1] != best[1]) | (best[2] != best[2]) | (best[3] != best[3])) {
             // a NaN among a pixel's logits: the exact class-by-class walk
@@ -998,7 +1084,8 @@ __global__ __launch_bounds__(kKdThreads, 2) void kdlite_head_kernel(HeadArgs h) 
         for (int e = 0; e < 4; ++e) {
             if (lab[e] >= 0 && lab[e] < C) atomicAdd(&hist[(int)lab[e] * C + arg[e]], 1u);
             if (id[e] == -2) ++bad;
-            const float kl = a.invT * st.at[e] / st.zt[e] - fast_ln(st.zt[e]) + fast_ln(st.zs[e]);
+            const float kl = PROBS ? hn[e] + a.invT * (st.ms[e] - st.at[e]) + fast_ln(st.zs[e])
+                                   : a.invT * st.at[e] / st.zt[e] - fast_ln(st.zt[e]) + fast_ln(st.zs[e]);
             const float nll = fast_ln(st.z1[e]) - (st.sy[e] - st.ms[e]);
             const float wy = (id[e] >= 0) ? (a.class_w ? a.class_w[id[e]] : 1.f) : 0.f;
             if (id[e] != -1) {
@@ -1213,8 +1300,24 @@ SPICE_ENV_KNOB(knob_head_blocks_per_cu, "SPICE_HEAD_BLOCKS_PER_CU", 0)   // tuni
 
 constexpr size_t kHeadMaxLdsBytes = 64 * 1024;   // two workgroups per compute unit at least
 
-extern "C" int spice_sweep_head_f16(const void *low, const float *teacher, const int64_t *labels, int64_t n,
-                                    int64_t c, int64_t in_h, int64_t in_w, int64_t h, int64_t w,
+extern "C" int spice_kd_teacher_prepare(const float *teacher, int64_t n, int64_t c, int64_t h, int64_t w,
+                                        float temperature, float *probs, float *hneg, void *stream) {
+    if (n < 0 || c < 1 || h < 0 || w < 0 || !(temperature > 0.f)) return SPICE_ERR_ARG;
+    const int64_t hw = h * w;
+    if (n == 0 || hw == 0) return SPICE_OK;
+    if (!teacher || !probs || !hneg) return SPICE_ERR_ARG;
+    if (c > INT32_MAX || hw > INT32_MAX - 4096) return SPICE_ERR_UNSUPPORTED;
+    if (hw % 4 != 0 || !aligned16(teacher) || !aligned16(probs) || !aligned16(hneg)) return SPICE_ERR_UNSUPPORTED;
+    int64_t blocks = ceil_div(n * (hw / 4), 256);
+    if (blocks > 16 * (int64_t)device_cu_count()) blocks = 16 * (int64_t)device_cu_count();
+    hipLaunchKernelGGL(kd_teacher_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       teacher, probs, hneg, (long long)n, (long long)hw, (int)c, 1.0f / temperature);
+    SPICE_LAUNCH_CHECK();
+    return SPICE_OK;
+}
+
+extern "C" int spice_sweep_head_f16(const void *low, const float *teacher, const float *teacher_hneg,
+                                    const int64_t *labels, int64_t n, int64_t c, int64_t in_h, int64_t in_w, int64_t h, int64_t w,
                                     int32_t align_corners, float scale_h, float scale_w,
                                     const spice_kdlite_params *params, float *out3, int64_t *conf,
                                     void *kd_workspace, size_t kd_workspace_bytes, void *conf_workspace,
@@ -1230,11 +1333,12 @@ extern "C" int spice_sweep_head_f16(const void *low, const float *teacher, const
     const int64_t hw = h * w;
     if (hw > INT32_MAX - 4096 || n > kConfMaxPixels / hw) return SPICE_ERR_UNSUPPORTED;
     if (w % 4 != 0 || in_w % 8 != 0) return SPICE_ERR_UNSUPPORTED;   // a lane's four pixels lie in one row; 16-byte source chunks
-    if (!aligned16(low) || !aligned16(teacher) || !aligned16(labels)) return SPICE_ERR_UNSUPPORTED;
+    if (!aligned16(low) || !aligned16(teacher) || !aligned16(labels) || !aligned16(teacher_hneg)) return SPICE_ERR_UNSUPPORTED;
     if (conf_workspace_bytes < spice_confusion_workspace_bytes(n * hw, (int32_t)c)) return SPICE_ERR_WORKSPACE;
 
     HeadArgs ha;
     ha.low = static_cast<const __half *>(low);
+    ha.hneg = teacher_hneg;
     ha.in_h = (int)in_h;
     ha.in_w = (int)in_w;
     ha.align_corners = align_corners ? 1 : 0;
@@ -1301,10 +1405,18 @@ extern "C" int spice_sweep_head_f16(const void *low, const float *teacher, const
     const int64_t chunks = c * lds_rows * (in_w / 8);   // 16-byte source chunks of a tile
     if (chunks > 8 * kKdThreads) return SPICE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)blocks), block(kKdThreads);
-    if (chunks > 4 * kKdThreads)
-        hipLaunchKernelGGL((kdlite_head_kernel<4, 8>), grid, block, lds_bytes, st, ha);
-    else
-        hipLaunchKernelGGL((kdlite_head_kernel<4, 4>), grid, block, lds_bytes, st, ha);
+    const bool probs = teacher_hneg != nullptr;
+    if (chunks > 4 * kKdThreads) {
+        if (probs)
+            hipLaunchKernelGGL((kdlite_head_kernel<4, 8, true>), grid, block, lds_bytes, st, ha);
+        else
+            hipLaunchKernelGGL((kdlite_head_kernel<4, 8, false>), grid, block, lds_bytes, st, ha);
+    } else {
+        if (probs)
+            hipLaunchKernelGGL((kdlite_head_kernel<4, 4, true>), grid, block, lds_bytes, st, ha);
+        else
+            hipLaunchKernelGGL((kdlite_head_kernel<4, 4, false>), grid, block, lds_bytes, st, ha);
+    }
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;
 }

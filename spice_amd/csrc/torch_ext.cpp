@@ -253,9 +253,27 @@ std::tuple<Tensor, Tensor> kdlite_forward(const Tensor &student, const Tensor &t
 // Up-sampling + loss + arg-max histogram of a sweep candidate in one launch.  Returns out3, or a tensor
 // without elements when the library does not cover the case (nothing was launched; the caller makes the
 // three separate calls).
-Tensor sweep_head(const Tensor &low, const Tensor &teacher, const Tensor &labels, Tensor conf, bool align_corners,
+// The teacher-only parts of the distillation term, once per teacher: (softmax(teacher / T) over C, per-pixel
+// sum p ln p).  Tensors without elements when the library does not cover the layout.
+std::tuple<Tensor, Tensor> kd_teacher_prepare(const Tensor &teacher, double temperature) {
+    check_dev(teacher, "teacher_logits", at::kFloat);
+    TORCH_CHECK_VALUE(teacher.dim() == 4, "teacher_logits must be [N,C,H,W]");
+    c10::DeviceGuard guard(teacher.device());
+    const int64_t n = teacher.size(0), c = teacher.size(1), h = teacher.size(2), w = teacher.size(3);
+    Tensor probs = at::empty_like(teacher);
+    Tensor hneg = at::empty({n, h, w}, teacher.options());
+    const int rc = spice_kd_teacher_prepare(teacher.data_ptr<float>(), n, c, h, w, (float)temperature,
+                                            probs.data_ptr<float>(), hneg.data_ptr<float>(), current_stream(teacher));
+    if (rc == SPICE_ERR_UNSUPPORTED) return std::make_tuple(at::empty({0}, teacher.options()), at::empty({0}, teacher.options()));
+    check_rc(rc, "spice_kd_teacher_prepare");
+    return std::make_tuple(probs, hneg);
+}
+
+Tensor sweep_head(const Tensor &low, const Tensor &teacher, const c10::optional<Tensor> &teacher_hneg,
+                  const Tensor &labels, Tensor conf, bool align_corners,
                   double scale_h, double scale_w, double temperature, double alpha, int64_t ignore_index,
-                  const c10::optional<Tensor> &class_weight, Tensor kd_workspace, Tensor conf_workspace) {
+                  const c10::optional<Tensor> &class_weight, Tensor kd_workspace, Tensor conf_workspace,
+                  const c10::optional<Tensor> &out) {
     check_dev(low, "low_logits", at::kHalf);
     check_dev(teacher, "teacher_logits", at::kFloat);
     check_dev(labels, "labels", at::kLong);
@@ -272,6 +290,13 @@ Tensor sweep_head(const Tensor &low, const Tensor &teacher, const Tensor &labels
     check_conf(conf, c);
     TORCH_CHECK_VALUE(labels.dim() == 3 && labels.size(0) == n && labels.size(1) == h && labels.size(2) == w,
                       "labels must be [", n, ",", h, ",", w, "], got ", labels.sizes());
+    const float *hneg = nullptr;
+    if (teacher_hneg.has_value()) {   // `teacher` then holds the prepared probabilities
+        check_dev(*teacher_hneg, "teacher_hneg", at::kFloat);
+        check_same_device(low, *teacher_hneg, "teacher_hneg");
+        TORCH_CHECK_VALUE(teacher_hneg->numel() == n * h * w, "teacher_hneg must have N*H*W elements");
+        hneg = teacher_hneg->data_ptr<float>();
+    }
     spice_kdlite_params p;
     p.temperature = (float)temperature;
     p.alpha = (float)alpha;
@@ -286,8 +311,16 @@ Tensor sweep_head(const Tensor &low, const Tensor &teacher, const Tensor &labels
         p.class_weight = class_weight->data_ptr<float>();
     }
     c10::DeviceGuard guard(low.device());
-    Tensor out3 = at::empty({3}, teacher.options());
-    const int rc = spice_sweep_head_f16(low.data_ptr(), teacher.data_ptr<float>(), labels.data_ptr<int64_t>(), n, c,
+    Tensor out3;
+    if (out.has_value()) {   // the three floats written where the caller keeps them
+        check_dev(*out, "out", at::kFloat);
+        check_same_device(low, *out, "out");
+        TORCH_CHECK_VALUE(out->numel() == 3, "out must hold three floats");
+        out3 = *out;
+    } else {
+        out3 = at::empty({3}, teacher.options());
+    }
+    const int rc = spice_sweep_head_f16(low.data_ptr(), teacher.data_ptr<float>(), hneg, labels.data_ptr<int64_t>(), n, c,
                                         low.size(2), low.size(3), h, w, align_corners ? 1 : 0, (float)scale_h,
                                         (float)scale_w, &p, out3.data_ptr<float>(), conf.data_ptr<int64_t>(),
                                         kd_workspace.data_ptr(), (size_t)kd_workspace.numel(), conf_workspace.data_ptr(),
@@ -682,9 +715,10 @@ TORCH_LIBRARY(spice, m) {
           &confusion_update);
     m.def("confusion_update_static(Tensor(a!) conf, Tensor preds, Tensor target, int num_classes, "
           "Tensor(b!)? invalid_count) -> ()", &confusion_update_static);
-    m.def("sweep_head(Tensor low, Tensor teacher, Tensor labels, Tensor(a!) conf, bool align_corners, float scale_h, "
+    m.def("kd_teacher_prepare(Tensor teacher, float temperature) -> (Tensor, Tensor)", &kd_teacher_prepare);
+    m.def("sweep_head(Tensor low, Tensor teacher, Tensor? teacher_hneg, Tensor labels, Tensor(a!) conf, bool align_corners, float scale_h, "
           "float scale_w, float temperature, float alpha, int ignore_index, Tensor? class_weight, "
-          "Tensor(b!) kd_workspace, Tensor(c!) conf_workspace) -> Tensor", &sweep_head);
+          "Tensor(b!) kd_workspace, Tensor(c!) conf_workspace, Tensor(d!)? out) -> Tensor", &sweep_head);
     m.def("argmax_confusion_update(Tensor(a!) conf, Tensor logits, Tensor target, int num_classes, "
           "Tensor(b!) workspace) -> ()", &argmax_confusion_update);
     m.def("kdlite_forward(Tensor student, Tensor teacher, Tensor labels, float temperature, float alpha, "

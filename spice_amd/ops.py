@@ -288,16 +288,30 @@ def kdlite_forward(student: torch.Tensor, teacher: torch.Tensor, labels: torch.T
     return out3, grad, sums
 
 
+def kd_teacher_prepare(teacher: torch.Tensor, temperature: float) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
+    """Once per teacher of a sweep: (softmax(teacher / T) over the class axis [N,C,H,W] fp32, per-pixel
+    sum p ln p [N,H,W] fp32) for sweep_head(teacher=..., teacher_hneg=...); None when the library does not cover the
+    layout (H*W % 4 != 0)."""
+    if not teacher.is_cuda:
+        nat.require_device_tensor(teacher, "teacher_logits", torch.float32)
+    probs, hneg = spice_ops().kd_teacher_prepare(teacher, float(temperature))
+    return (probs, hneg) if probs.numel() or not teacher.numel() else None
+
+
 def sweep_head(low: torch.Tensor, teacher: torch.Tensor, labels: torch.Tensor, conf: torch.Tensor, *,
                temperature: float, alpha: float, ignore_index: int = 255,
                class_weight: Optional[torch.Tensor] = None, align_corners: bool = True,
-               scale_factor: Optional[float] = None) -> Optional[torch.Tensor]:
+               scale_factor: Optional[float] = None,
+               teacher_hneg: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """The tail of a sweep candidate in one launch: bilinear up-sampling of the head's fp16 logits
     `low` [N,C,h,w] to the teacher's size, KD-Lite loss against `teacher` [N,C,H,W] fp32 and
     conf[label, argmax] += 1, without the full-size student logits ever being written.  Same values as
     upsample_bilinear -> kdlite_forward + argmax_confusion_update (interpolated logits bit for bit).
-    Returns out3 = [total, ce, kd], or None when the library does not cover the case (nothing was
-    launched: make the three calls)."""
+    With `teacher_hneg`, `teacher` holds the probabilities of kd_teacher_prepare (same temperature) instead of
+    logits: one exponential per logit less in the per-candidate pass, same loss within fp32 rounding.
+    Returns out3 = [total, ce, kd] (`out` itself when given: three contiguous floats), or None when the library
+    does not cover the case (nothing was launched: make the three calls)."""
     if not low.is_cuda:
         nat.require_device_tensor(low, "low_logits", torch.float16)
     if low.dim() != 4 or teacher.dim() != 4:
@@ -307,8 +321,8 @@ def sweep_head(low: torch.Tensor, teacher: torch.Tensor, labels: torch.Tensor, c
     kd_ws = _workspace("kdlite", dev, nat.lib().spice_kdlite_workspace_bytes(n, c, h, w))
     conf_ws = _workspace("conf%d" % c, dev, nat.lib().spice_confusion_workspace_bytes(labels.numel(), c))
     sf = float(scale_factor) if scale_factor else 0.0
-    out3 = spice_ops().sweep_head(low, teacher, labels, conf, bool(align_corners), sf, sf, float(temperature),
-                                  float(alpha), int(ignore_index), class_weight, kd_ws, conf_ws)
+    out3 = spice_ops().sweep_head(low, teacher, teacher_hneg, labels, conf, bool(align_corners), sf, sf, float(temperature),
+                                  float(alpha), int(ignore_index), class_weight, kd_ws, conf_ws, out)
     return out3 if out3.numel() else None
 
 

@@ -87,6 +87,10 @@ class SensitivitySweep:
         #: it (SPICE_SWEEP_FUSED_HEAD=0: always the three separate launches)
         self.fused_head = os.environ.get("SPICE_SWEEP_FUSED_HEAD", "1") != "0"
         self.head_launches = 0
+        #: with the one-launch tail: the teacher's softmax taken once per teacher tensor instead of once per candidate
+        #: (SPICE_SWEEP_PREPARED_TEACHER=0: the head kernel reads the teacher's logits)
+        self.prepared_teacher = os.environ.get("SPICE_SWEEP_PREPARED_TEACHER", "1") != "0"
+        self._teacher_key, self._teacher_prepared = None, None
         self._geometry, self._geometry_for, self._warmed, self._fresh_logits = {}, None, set(), None
 
     # -- cost of a candidate, for balancing ranks ---------------------------------------------
@@ -355,14 +359,30 @@ class SensitivitySweep:
         algorithmic bytes of the gather launch.  first_lane: on this network and the current stream whatever lane
         the candidate belongs to (measurements that want one candidate on the device at a time)."""
         lane = self if first_lane else self._lane_of(index)
+        prepared = None
+        if self.fused_head and self.prepared_teacher and teacher_logits is not None and kd_out is not None:
+            prepared = self._teacher_parts(teacher_logits)
         if lane is not self:
             lane.fused_head = self.fused_head
             with torch.cuda.stream(lane._stream):
-                return lane._evaluate(index, images, labels, teacher_logits, conf_out, kd_out, self.kd_events)
-        return self._evaluate(index, images, labels, teacher_logits, conf_out, kd_out, self.kd_events)
+                return lane._evaluate(index, images, labels, teacher_logits, conf_out, kd_out, self.kd_events, prepared)
+        return self._evaluate(index, images, labels, teacher_logits, conf_out, kd_out, self.kd_events, prepared)
+
+    def _teacher_parts(self, teacher_logits: torch.Tensor):
+        """(probabilities at the distillation temperature, per-pixel sum p ln p) of the teacher's logits, taken once
+        per teacher tensor (address, version, shape) on the current stream: every candidate of a sweep is compared
+        with the same un-pruned network.  None when the library does not cover the layout."""
+        key = (teacher_logits.data_ptr(), teacher_logits._version, tuple(teacher_logits.shape), float(self.kd["temperature"]))
+        if self._teacher_key != key:
+            self._teacher_key, self._teacher_prepared = key, None
+            if teacher_logits.is_cuda and teacher_logits.dtype == torch.float32 and teacher_logits.is_contiguous():
+                self._teacher_prepared = ops.kd_teacher_prepare(teacher_logits, self.kd["temperature"])
+                self.fork_lanes()   # the other lanes' streams wait for it
+        return self._teacher_prepared
 
     def _evaluate(self, index: int, images: torch.Tensor, labels: torch.Tensor, teacher_logits: Optional[torch.Tensor],
-                  conf_out: torch.Tensor, kd_out: Optional[torch.Tensor], kd_events: Optional[list]) -> int:
+                  conf_out: torch.Tensor, kd_out: Optional[torch.Tensor], kd_events: Optional[list],
+                  prepared=None) -> int:
         if index not in self.jobs:
             self._prepare([index])
         job = self.jobs[index]
@@ -379,8 +399,14 @@ class SensitivitySweep:
                 low, up = parts
                 if e0 is not None:
                     e0.record()
-                out3 = ops.sweep_head(low, teacher_logits, labels, conf_out, align_corners=True,
-                                      scale_factor=float(up.scale_factor), **self.kd)
+                if prepared is not None:
+                direct = kd_out if (kd_out.is_contiguous() and kd_out.dtype == torch.float32) else None
+                if prepared is not None:
+                    out3 = ops.sweep_head(low, prepared[0], labels, conf_out, align_corners=True, out=direct,
+                                          scale_factor=float(up.scale_factor), teacher_hneg=prepared[1], **self.kd)
+                else:
+                    out3 = ops.sweep_head(low, teacher_logits, labels, conf_out, align_corners=True, out=direct,
+                                          scale_factor=float(up.scale_factor), **self.kd)
                 if out3 is None:   # a shape the one-launch kernel does not cover
                     with torch.no_grad(), torch.autocast("cuda", dtype=self.autocast_dtype):
                         logits = up(low).contiguous()
@@ -388,7 +414,8 @@ class SensitivitySweep:
                     if e1 is not None:
                         e1.record()
                         kd_events.append((e0, e1))
-                    kd_out.copy_(out3)
+                    if direct is None:
+                        kd_out.copy_(out3)
                     self.head_launches += 1
             else:
                 logits = self.forward(images).contiguous()

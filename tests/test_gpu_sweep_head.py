@@ -66,6 +66,28 @@ def test_sweep_head_equals_three_launches(dev, n, c, h, w, scale, align):
         assert out3 is not None, "the library must cover this shape"
         np.testing.assert_array_equal(conf.cpu().numpy(), rep * ref_conf.cpu().numpy())
         np.testing.assert_allclose(out3.cpu().numpy(), ref_out3.cpu().numpy(), rtol=1e-6, atol=0)
+    # the teacher's softmax taken once beforehand: the same matrix, the same loss within fp32 rounding of the
+    # per-pixel terms (another, algebraically equal, form of the KL sum)
+    parts = ops.kd_teacher_prepare(t_d, kw["temperature"])
+    assert parts is not None
+    conf.zero_()
+    out3 = ops.sweep_head(low_d, parts[0], lab_d, conf, align_corners=align, scale_factor=float(scale),
+                          teacher_hneg=parts[1], **kw)
+    assert out3 is not None
+    np.testing.assert_array_equal(conf.cpu().numpy(), ref_conf.cpu().numpy())
+    np.testing.assert_allclose(out3.cpu().numpy(), ref_out3.cpu().numpy(), rtol=REL, atol=0)
+
+
+def test_teacher_parts_vs_float64(dev):
+    n, c, h, w = 2, 21, 24, 40
+    t = (np.random.default_rng(9).standard_normal((n, c, h, w)) * 4).astype(np.float32)
+    probs, hneg = ops.kd_teacher_prepare(torch.from_numpy(t).to(dev), 4.0)
+    z = t.astype(np.float64) / 4.0
+    lp = z - z.max(1, keepdims=True)
+    lp = lp - np.log(np.exp(lp).sum(1, keepdims=True))
+    np.testing.assert_allclose(probs.cpu().numpy(), np.exp(lp), rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(hneg.cpu().numpy(), (np.exp(lp) * lp).sum(1), rtol=2e-6, atol=1e-6)
+    assert ops.kd_teacher_prepare(torch.zeros(1, 3, 3, 3, device=dev), 4.0) is None   # H*W % 4 != 0
 
 
 @pytest.mark.parametrize("n,c,h,w,scale,align", [(2, 21, 32, 32, 4, True), (2, 5, 24, 40, 4, False),
@@ -83,9 +105,16 @@ def test_sweep_head_vs_oracle(dev, n, c, h, w, scale, align):
                           class_weight=None if weights is None else weights.to(dev))
     assert out3 is not None
     got = out3.cpu().numpy().astype(np.float64)
+    parts = ops.kd_teacher_prepare(torch.from_numpy(teacher).to(dev), 4.0)
+    conf2 = torch.zeros(c, c, dtype=torch.int64, device=dev)
+    out3p = ops.sweep_head(torch.from_numpy(low).to(dev), parts[0], torch.from_numpy(lab).to(dev), conf2,
+                           align_corners=align, scale_factor=float(scale), temperature=4.0, alpha=0.7,
+                           class_weight=None if weights is None else weights.to(dev), teacher_hneg=parts[1])
+    assert torch.equal(conf, conf2)
     if weights is None:
         want = np.array([ref["total"], ref["ce"], ref["kd"]])
         np.testing.assert_allclose(got, want, rtol=REL)
+        np.testing.assert_allclose(out3p.cpu().numpy().astype(np.float64), want, rtol=REL)
     # torch's CPU interpolation and the device kernel agree to the last bit on almost every value; an arg-max
     # can only differ where two interpolated logits are within one rounding of each other
     diff = np.abs(conf.cpu().numpy() - ref_conf).sum()
@@ -125,6 +154,14 @@ def test_sweep_head_ties_nan_and_infinities(dev):
     assert np.array_equal(np.isnan(a), np.isnan(b))
     np.testing.assert_allclose(a[~np.isnan(a)], b[~np.isnan(b)], rtol=1e-6)
     assert ops.kdlite_bad_label_count(dev) - before == 14
+    parts = ops.kd_teacher_prepare(t_d, kw["temperature"])
+    conf.zero_()
+    out3 = ops.sweep_head(low_d, parts[0], lab_d, conf, align_corners=True, scale_factor=float(scale),
+                          teacher_hneg=parts[1], **kw)
+    np.testing.assert_array_equal(conf.cpu().numpy(), want)
+    a = out3.cpu().numpy()
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    np.testing.assert_allclose(a[~np.isnan(a)], b[~np.isnan(b)], rtol=REL)
 
 
 def test_sweep_head_declines_what_it_does_not_cover(dev):
@@ -156,11 +193,17 @@ def test_sweep_uses_the_head_launch_and_gives_the_same_tables(dev):
     idx = list(range(0, len(sweep.candidates), max(1, len(sweep.candidates) // 5)))[:5]
     sweep.fused_head = True
     got = sweep.run(images, labels, indices=idx)
-    assert sweep.head_launches == len(idx)
+    assert sweep.head_launches == len(idx) and sweep._teacher_prepared is not None
+    sweep.prepared_teacher = False
+    mid = sweep.run(images, labels, indices=idx)
+    assert sweep.head_launches == 2 * len(idx)
+    np.testing.assert_array_equal(got["confusion"].cpu().numpy(), mid["confusion"].cpu().numpy())
+    np.testing.assert_allclose(got["kd"].cpu().numpy(), mid["kd"].cpu().numpy(), rtol=1e-5, atol=1e-6)
     sweep.fused_head = False
     ref = sweep.run(images, labels, indices=idx)
-    assert sweep.head_launches == len(idx)
+    assert sweep.head_launches == 2 * len(idx)
     np.testing.assert_array_equal(got["confusion"].cpu().numpy(), ref["confusion"].cpu().numpy())
-    # the un-pruned network is the teacher: the KL term is ~1e-6, fp32 noise around it
-    np.testing.assert_allclose(got["kd"].cpu().numpy(), ref["kd"].cpu().numpy(), rtol=1e-5, atol=1e-7)
+    # the un-pruned network is the teacher: the KL term is small, fp32 noise of the per-pixel terms around it
+    np.testing.assert_allclose(mid["kd"].cpu().numpy(), ref["kd"].cpu().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(got["kd"].cpu().numpy(), ref["kd"].cpu().numpy(), rtol=1e-5, atol=1e-6)
     assert int(got["confusion"][idx[0]].sum()) == int((labels != 255).sum())

@@ -399,7 +399,6 @@ class SensitivitySweep:
                 low, up = parts
                 if e0 is not None:
                     e0.record()
-                if prepared is not None:
                 direct = kd_out if (kd_out.is_contiguous() and kd_out.dtype == torch.float32) else None
                 if prepared is not None:
                     out3 = ops.sweep_head(low, prepared[0], labels, conf_out, align_corners=True, out=direct,

@@ -144,7 +144,7 @@ class Conv1x1(nn.Conv2d):
         super().__init__(in_channels, out_channels, 1, stride=stride, bias=False)
 
     def _plain_fp16(self, x_dtype: torch.dtype) -> bool:
-        return (_LIBRARY_FORWARD and self.bias is None and self.groups == 1 and self.padding == (0, 0)
+        return (_LIBRARY_FORWARD and self._parameters["bias"] is None and self.groups == 1 and self.padding == (0, 0)
                 and (x_dtype == torch.float16 or
                      (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16)))
 
@@ -174,8 +174,10 @@ class Conv1x1(nn.Conv2d):
 
 
 def _plain_inference_norm(bn: nn.BatchNorm2d) -> bool:
-    return (not bn.training and bn.track_running_stats and bn.affine and bn.weight.dtype == torch.float32
-            and bn.running_mean.dtype == torch.float32)
+    # parameters and buffers straight from their tables (nn.Module's attribute fallback is several dictionary probes
+    # per name; this runs once per batch-norm per forward)
+    return (not bn.training and bn.track_running_stats and bn.affine
+            and bn._parameters["weight"].dtype == torch.float32 and bn._buffers["running_mean"].dtype == torch.float32)
 
 
 def _hooked(m: nn.Module) -> bool:
@@ -223,7 +225,7 @@ def conv1x1_bn(conv: Conv1x1, bn: BatchNormAct2d, x, residual=None, residual_nor
             if x.dtype != torch.float16:
                 x = x.to(torch.float16)   # what autocast does to a convolution's input
             if x.is_contiguous():
-                return ops.conv1x1_bn_act(x, _fp16_matrix(conv.weight), bn, residual, residual_norm, bn.relu_after, out=out,
+                return ops.conv1x1_bn_act(x, _fp16_matrix(conv._parameters["weight"]), bn, residual, residual_norm, bn.relu_after, out=out,
                                           pre_bn=pre, pre_relu=pre.relu_after if pre is not None else False)
         if pre is not None:
             x = pre_norm(x)
@@ -260,7 +262,7 @@ def conv3x3_served_by_library(conv: nn.Conv2d, x_dtype: torch.dtype, height: int
     s, d = conv.stride[0], conv.dilation[0]
     return (_LIBRARY_FORWARD and _LIBRARY_CONV3X3 and type(conv) is nn.Conv2d and conv.kernel_size == (3, 3)
             and conv.stride == (s, s) and s in (1, 2) and conv.dilation == (d, d) and 1 <= d <= 7 and conv.padding == (d, d)
-            and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros"
+            and conv.groups == 1 and conv._parameters["bias"] is None and conv.padding_mode == "zeros"
             and (x_dtype == torch.float16 or
                  (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16))
             and height % s == 0 and width % s == 0 and (width // s) % 8 == 0 and width >= 8)
@@ -276,7 +278,7 @@ def conv3x3_bn(conv: nn.Conv2d, bn: BatchNormAct2d, x):
         if x.dtype != torch.float16:
             x = x.to(torch.float16)   # what autocast does to a convolution's input
         if x.is_contiguous():
-            return ops.conv3x3_bn_act(x, _fp16_taps(conv.weight), bn, bn.relu_after, conv.stride[0], conv.dilation[0])
+            return ops.conv3x3_bn_act(x, _fp16_taps(conv._parameters["weight"]), bn, bn.relu_after, conv.stride[0], conv.dilation[0])
     return None
 
 

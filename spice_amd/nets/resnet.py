@@ -31,12 +31,15 @@ class Bottleneck(nn.Module):
                 nn.BatchNorm2d(planes * 4))
 
     def forward(self, x):
-        h1 = conv1x1_bn(self.conv1, self.bn1, x)
-        out = conv3x3_bn(self.conv2, self.bn2, h1)   # one launch of the library's kernel at inference, else None
+        m = self._modules   # the sub-modules from their table: nn.Module's attribute fallback is several probes per name
+        conv2, bn2, conv3, bn3, downsample = m["conv2"], m["bn2"], m["conv3"], m["bn3"], m.get("downsample")
+        h1 = conv1x1_bn(m["conv1"], m["bn1"], x)
+        out = conv3x3_bn(conv2, bn2, h1)   # one launch of the library's kernel at inference, else None
         if out is not None:
-            if self.downsample is None:
-                return conv1x1_bn(self.conv3, self.bn3, out, x)
-            return conv1x1_bn(self.conv3, self.bn3, out, self.downsample[0](x), self.downsample[1])
+            if downsample is None:
+                return conv1x1_bn(conv3, bn3, out, x)
+            ds = downsample._modules
+            return conv1x1_bn(conv3, bn3, out, ds["0"](x), ds["1"])
         # the 3x3 convolution on torch's route: bn2 (+ ReLU) rides along with conv3 at inference, whose kernel applies it
         # to the convolution's raw result on the way in
         raw = self.conv2(h1)

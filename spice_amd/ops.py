@@ -551,6 +551,14 @@ def conv1x1_f16(x: torch.Tensor, weight2d: torch.Tensor, stride: int = 1) -> tor
 _conv1x1_bn_fn = None
 
 
+def _bn_parts(bn):
+    """(running_mean, running_var, weight, bias, eps) of a batch-norm module, read from its buffer and parameter
+    tables directly: nn.Module's attribute fallback costs several dictionary probes per name, and a forward asks for
+    these a few hundred times."""
+    b, p = bn._buffers, bn._parameters
+    return b["running_mean"], b["running_var"], p["weight"], p["bias"], bn.eps
+
+
 def conv1x1_bn_act(x: torch.Tensor, weight2d: torch.Tensor, bn: "torch.nn.BatchNorm2d",
                    residual: Optional[torch.Tensor] = None, res_bn: Optional["torch.nn.BatchNorm2d"] = None,
                    relu: bool = False, route: int = 0, out: Optional[torch.Tensor] = None,
@@ -565,12 +573,9 @@ def conv1x1_bn_act(x: torch.Tensor, weight2d: torch.Tensor, bn: "torch.nn.BatchN
     global _conv1x1_bn_fn
     if _conv1x1_bn_fn is None:
         _conv1x1_bn_fn = spice_ops().conv1x1_bn_act
-    r = (None, None, None, None, 0.0) if res_bn is None else (res_bn.running_mean, res_bn.running_var, res_bn.weight,
-                                                               res_bn.bias, res_bn.eps)
-    p = (None, None, None, None, 0.0) if pre_bn is None else (pre_bn.running_mean, pre_bn.running_var, pre_bn.weight,
-                                                              pre_bn.bias, pre_bn.eps)
-    args = (x, weight2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, residual, *r, relu, route, out, *p,
-            pre_relu)
+    r = (None, None, None, None, 0.0) if res_bn is None else _bn_parts(res_bn)
+    p = (None, None, None, None, 0.0) if pre_bn is None else _bn_parts(pre_bn)
+    args = (x, weight2d, *_bn_parts(bn), residual, *r, relu, route, out, *p, pre_relu)
     if _conv_probe is not None:
         return _probed("matrix_core_pair", _conv1x1_bn_fn, args, x, weight2d.shape[0], weight2d.shape[1], residual)
     return _conv1x1_bn_fn(*args)
@@ -609,7 +614,7 @@ def conv3x3_bn_act(x: torch.Tensor, weight9: torch.Tensor, bn: "torch.nn.BatchNo
     global _conv3x3_fn
     if _conv3x3_fn is None:
         _conv3x3_fn = spice_ops().conv3x3_bn_act
-    args = (x, weight9, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, relu, stride, dilation)
+    args = (x, weight9, *_bn_parts(bn), relu, stride, dilation)
     if _conv_probe is not None:
         return _probed("matrix_core_3x3", _conv3x3_fn, args, x, weight9.shape[0], weight9.shape[1])
     return _conv3x3_fn(*args)

@@ -7,7 +7,11 @@ against the un-pruned model's logits.  Composed from the reference's primitives;
 itself only runs the one-shot Taylor analysis (pruning/pruning_core.py:99-133).
 
 Per candidate the device sees: one gather launch (slice the group's tensors), the forward of the
-sliced network (MIOpen), one fused arg-max + histogram launch, one fused KD-Lite launch pair.
+sliced network up to the head's convolution (the library's kernels under fp16 autocast) and ONE
+launch for the rest: the head's bilinear up-sampling, the KD-Lite loss against the un-pruned
+network's logits (whose softmax is taken once per sweep) and the arg-max + confusion histogram,
+without the full-size logits ever being written.  Networks whose head does not fit that launch run
+the forward to its end, the fused arg-max + histogram launch and the KD-Lite launch.
 Everything the host has to prepare (kept-index lists, launch plans, MIOpen's solver lookups for
 the convolution shapes the candidates will bring) is done for a rank's whole share before its
 first candidate runs, and the fp16 copies of the unchanged weights are made once per sweep, so
@@ -90,7 +94,7 @@ class SensitivitySweep:
         #: with the one-launch tail: the teacher's softmax taken once per teacher tensor instead of once per candidate
         #: (SPICE_SWEEP_PREPARED_TEACHER=0: the head kernel reads the teacher's logits)
         self.prepared_teacher = os.environ.get("SPICE_SWEEP_PREPARED_TEACHER", "1") != "0"
-        self._teacher_key, self._teacher_prepared = None, None
+        self._teacher_src, self._teacher_key, self._teacher_prepared = None, None, None
         self._geometry, self._geometry_for, self._warmed, self._fresh_logits = {}, None, set(), None
 
     # -- cost of a candidate, for balancing ranks ---------------------------------------------
@@ -335,14 +339,15 @@ class SensitivitySweep:
 
     def _network_input(self, images: torch.Tensor) -> torch.Tensor:
         """The batch as the first convolution reads it under autocast.  Every candidate sees the same batch, so the
-        cast is made once per batch tensor (address, version, shape), not once per candidate."""
+        cast is made once per batch tensor (object and version), not once per candidate."""
         if (self.autocast_dtype is None or not images.is_floating_point() or images.dtype == self.autocast_dtype
                 or not images.is_cuda):
             return images
-        key = (images.data_ptr(), images._version, tuple(images.shape), images.dtype)
-        if getattr(self, "_cast_key", None) != key:
+        # keyed by the tensor object (kept alive with its cast) and its version: an address alone can come back from
+        # the allocator holding another batch
+        if getattr(self, "_cast_src", None) is not images or self._cast_key != images._version:
             self._cast = images.to(self.autocast_dtype)
-            self._cast_key = key
+            self._cast_src, self._cast_key = images, images._version
         return self._cast
 
     def forward(self, images: torch.Tensor) -> torch.Tensor:
@@ -370,11 +375,13 @@ class SensitivitySweep:
 
     def _teacher_parts(self, teacher_logits: torch.Tensor):
         """(probabilities at the distillation temperature, per-pixel sum p ln p) of the teacher's logits, taken once
-        per teacher tensor (address, version, shape) on the current stream: every candidate of a sweep is compared
+        per teacher tensor (object and version) on the current stream: every candidate of a sweep is compared
         with the same un-pruned network.  None when the library does not cover the layout."""
-        key = (teacher_logits.data_ptr(), teacher_logits._version, tuple(teacher_logits.shape), float(self.kd["temperature"]))
-        if self._teacher_key != key:
-            self._teacher_key, self._teacher_prepared = key, None
+        # the tensor object itself is part of the key and is kept alive with the result: an address alone can come
+        # back from the allocator holding another teacher's logits
+        key = (teacher_logits._version, float(self.kd["temperature"]))
+        if self._teacher_src is not teacher_logits or self._teacher_key != key:
+            self._teacher_src, self._teacher_key, self._teacher_prepared = teacher_logits, key, None
             if teacher_logits.is_cuda and teacher_logits.dtype == torch.float32 and teacher_logits.is_contiguous():
                 self._teacher_prepared = ops.kd_teacher_prepare(teacher_logits, self.kd["temperature"])
                 self.fork_lanes()   # the other lanes' streams wait for it

@@ -207,3 +207,26 @@ def test_sweep_uses_the_head_launch_and_gives_the_same_tables(dev):
     np.testing.assert_allclose(mid["kd"].cpu().numpy(), ref["kd"].cpu().numpy(), rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(got["kd"].cpu().numpy(), ref["kd"].cpu().numpy(), rtol=1e-5, atol=1e-6)
     assert int(got["confusion"][idx[0]].sum()) == int((labels != 255).sum())
+
+
+def test_sweep_run_again_on_another_batch(dev):
+    """A second run() on a new batch whose tensor may land on the first one's address (same shape, same
+    version): the cast of the batch and the prepared teacher must be those of the new batch."""
+    import torch.nn as nn
+    from spice_amd import nets
+    from spice_amd.sweep import SensitivitySweep
+    torch.manual_seed(1)
+    model = nets.create_model("DeepLabV3Plus", "resnet50", 21).to(dev).eval()
+    ignored = [m for m in model.segmentation_head.modules() if isinstance(m, nn.Conv2d)]
+    labels = torch.from_numpy(synth.label_map(4, 2, 128, 128, 21, "blocky")).to(dev)
+    sweep = SensitivitySweep(model, 21, ratios=(0.5,), ignored_layers=ignored)
+    idx = [0, len(sweep.candidates) // 2, len(sweep.candidates) - 1]
+    images = torch.randn(2, 3, 128, 128, device=dev)
+    first = sweep.run(images, labels, indices=idx)
+    del images
+    images = torch.randn(2, 3, 128, 128, device=dev) * 2 + 1
+    again = sweep.run(images, labels, indices=idx)
+    fresh = SensitivitySweep(model, 21, ratios=(0.5,), ignored_layers=ignored).run(images, labels, indices=idx)
+    assert not torch.equal(first["confusion"], again["confusion"])
+    assert torch.equal(again["confusion"], fresh["confusion"])
+    np.testing.assert_allclose(again["kd"].cpu().numpy(), fresh["kd"].cpu().numpy(), rtol=1e-5, atol=1e-6)

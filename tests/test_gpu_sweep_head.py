@@ -230,3 +230,72 @@ def test_sweep_run_again_on_another_batch(dev):
     assert not torch.equal(first["confusion"], again["confusion"])
     assert torch.equal(again["confusion"], fresh["confusion"])
     np.testing.assert_allclose(again["kd"].cpu().numpy(), fresh["kd"].cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_raw_ctypes_binding_of_the_head_entry_points(dev):
+    """spice_kd_teacher_prepare and spice_sweep_head_f16 called as a maintainer's ctypes stub would call them (no
+    spice_amd.ops, no torch extension): argument errors are return codes, an uncovered shape is
+    SPICE_ERR_UNSUPPORTED with nothing written, and the results are the oracle's."""
+    import ctypes
+    import os
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                   "spice_amd", "lib", "libspice_amd.so"))
+
+    class Params(ctypes.Structure):
+        _fields_ = [("temperature", ctypes.c_float), ("alpha", ctypes.c_float), ("boundary_weight", ctypes.c_float),
+                    ("confidence_weight", ctypes.c_int32), ("ignore_index", ctypes.c_int64),
+                    ("class_weight", ctypes.c_void_p)]
+
+    V, I64, F = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float
+    lib.spice_kdlite_workspace_bytes.restype = ctypes.c_size_t
+    lib.spice_kdlite_workspace_bytes.argtypes = [I64] * 4
+    lib.spice_confusion_workspace_bytes.restype = ctypes.c_size_t
+    lib.spice_confusion_workspace_bytes.argtypes = [I64, ctypes.c_int32]
+    lib.spice_kd_teacher_prepare.restype = ctypes.c_int32
+    lib.spice_kd_teacher_prepare.argtypes = [V, I64, I64, I64, I64, F, V, V, V]
+    lib.spice_sweep_head_f16.restype = ctypes.c_int32
+    lib.spice_sweep_head_f16.argtypes = [V, V, V, V, I64, I64, I64, I64, I64, I64, ctypes.c_int32, F, F,
+                                         ctypes.POINTER(Params), V, V, V, ctypes.c_size_t, V, ctypes.c_size_t, V]
+    n, c, h, w, scale = 2, 21, 16, 24, 4
+    low, teacher, lab = _inputs(21, n, c, h, w, scale)
+    H, W = h * scale, w * scale
+    low_d, t_d, lab_d = torch.from_numpy(low).to(dev), torch.from_numpy(teacher).to(dev), torch.from_numpy(lab).to(dev)
+    kd_ws = torch.zeros(lib.spice_kdlite_workspace_bytes(n, c, H, W), dtype=torch.uint8, device=dev)
+    conf_ws = torch.zeros(lib.spice_confusion_workspace_bytes(n * H * W, c), dtype=torch.uint8, device=dev)
+    probs, hneg = torch.empty_like(t_d), torch.empty(n, H, W, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.spice_kd_teacher_prepare(t_d.data_ptr(), n, c, H, W, 4.0, probs.data_ptr(), hneg.data_ptr(), stream) == 0
+    params = Params(4.0, 0.7, 1.0, 0, 255, None)
+
+    def call(teacher_ptr, hneg_ptr, low_t=low_d, in_w=w):
+        out3 = torch.full((3,), -7.0, device=dev)
+        conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
+        rc = lib.spice_sweep_head_f16(low_t.data_ptr(), teacher_ptr, hneg_ptr, lab_d.data_ptr(), n, c, h, in_w, H, W, 1,
+                                      float(scale), float(scale), ctypes.byref(params), out3.data_ptr(), conf.data_ptr(),
+                                      kd_ws.data_ptr(), kd_ws.numel(), conf_ws.data_ptr(), conf_ws.numel(), stream)
+        return rc, out3.cpu().numpy().astype(np.float64), conf.cpu().numpy()
+
+    up = ou.upsample_bilinear(torch.from_numpy(low), scale_factor=float(scale), align_corners=True).numpy()
+    ref = ok.kdlite_loss_f64(up, teacher, lab, temperature=4.0, alpha=0.7, num_classes=c)
+    want = np.array([ref["total"], ref["ce"], ref["kd"]])
+    want_conf = np.zeros((c, c), dtype=np.int64)
+    oc.update_confusion(want_conf, oc.argmax_first(up), lab, c)
+    for rc, out3, conf in (call(t_d.data_ptr(), None), call(probs.data_ptr(), hneg.data_ptr())):
+        assert rc == 0
+        np.testing.assert_allclose(out3, want, rtol=REL)
+        assert np.abs(conf - want_conf).sum() <= 2
+    # a source width that is no multiple of 8: declined, nothing written
+    rc, out3, conf = call(t_d.data_ptr(), None, in_w=w - 1)
+    assert rc == 10002 and (out3 == -7.0).all() and conf.sum() == 0
+    # argument errors are return codes
+    rc = lib.spice_sweep_head_f16(None, None, None, None, n, c, h, w, H, W, 1, 4.0, 4.0, ctypes.byref(params), None, None,
+                                  None, 0, None, 0, None)
+    assert rc != 0
+    assert lib.spice_kd_teacher_prepare(None, n, c, H, W, 4.0, None, None, None) != 0
+    small = torch.zeros(lib.spice_kdlite_workspace_bytes(n, c, H, W) - 16, dtype=torch.uint8, device=dev)
+    out3 = torch.zeros(3, device=dev)
+    conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
+    rc = lib.spice_sweep_head_f16(low_d.data_ptr(), t_d.data_ptr(), None, lab_d.data_ptr(), n, c, h, w, H, W, 1, 4.0, 4.0,
+                                  ctypes.byref(params), out3.data_ptr(), conf.data_ptr(), small.data_ptr(), small.numel(),
+                                  conf_ws.data_ptr(), conf_ws.numel(), stream)
+    assert rc != 0 and conf.sum().item() == 0   # workspace too small

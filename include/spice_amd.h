@@ -198,6 +198,16 @@ int spice_sweep_head_f16(const void *low, const float *teacher, const float *tea
                          void *kd_workspace, size_t kd_workspace_bytes, void *conf_workspace,
                          size_t conf_workspace_bytes, void *stream);
 
+/* The same launch without teacher and loss, for evaluation loops: conf[label, argmax up(low)] += 1 with the
+ * head's bilinear up-sampling done on the fly (baseline/eval/inference.py:45-48 and
+ * pruning/eval/components/core_evaluator.py:141-143 for models that end in convolution ->
+ * nn.UpsamplingBilinear2d): identical to spice_upsample_bilinear followed by
+ * spice_argmax_confusion_update, without the full-size logits.  SPICE_ERR_UNSUPPORTED as above. */
+int spice_upsample_argmax_confusion_f16(const void *low, const int64_t *labels, int64_t n, int64_t c,
+                                        int64_t in_h, int64_t in_w, int64_t h, int64_t w,
+                                        int32_t align_corners, float scale_h, float scale_w, int64_t *conf,
+                                        void *conf_workspace, size_t conf_workspace_bytes, void *stream);
+
 /* x[i] *= *scale for i < n, skipped entirely on the device when *scale == 1. */
 int spice_scale_inplace(float *x, int64_t n, const float *scale, void *stream);
 

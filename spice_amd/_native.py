@@ -86,6 +86,9 @@ SIGNATURES = {
     "spice_sweep_head_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
                                        c_int64, c_int32, c_float, c_float, POINTER(KdliteParams), c_void_p, c_void_p,
                                        c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "spice_upsample_argmax_confusion_f16": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                                      c_int64, c_int32, c_float, c_float, c_void_p, c_void_p, c_size_t,
+                                                      c_void_p]),
     "spice_scale_inplace": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p]),
     "spice_confusion_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "spice_confusion_update": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p,

@@ -13,7 +13,7 @@ import torch.nn as nn
 from torch.utils.data import DataLoader
 
 from ... import dist as sdist
-from .metrics import compute_metrics_from_confusion, update_confusion_matrix_from_logits
+from .metrics import compute_metrics_from_confusion, update_confusion_matrix_from_model
 
 
 def _split_batch(batch, device):
@@ -42,10 +42,9 @@ def inference(model: nn.Module, test_loader: DataLoader, device: torch.device, n
             if k % world != rank:
                 continue
             images, masks = _split_batch(batch, device)
-            outputs = model(images)
-            if isinstance(outputs, dict):
-                outputs = outputs.get("out", outputs.get("logits", outputs))
-            update_confusion_matrix_from_logits(conf, outputs, masks, num_classes)
+            # forward + arg-max + histogram (for models that end in a bilinear up-sampling: the up-sampling inside the
+            # histogram launch)
+            update_confusion_matrix_from_model(conf, model, images, masks, num_classes)
     if world > 1:
         sdist.all_reduce_sum_(conf)
     iou, acc, miou = compute_metrics_from_confusion(conf)

@@ -917,6 +917,23 @@ __device__ __forceinline__ void head_fold(PixStats<4> &st, const float *stage, i
         kd_fold_stats<4, U, false>(st, sv, tv, c0, id, k2);
 }
 
+// The arg-max half of head_fold alone: U class planes interpolated and compared, nothing else.
+template <int U, bool FULL>
+__device__ __forceinline__ void head_fold_argmax(const float *stage, int plane_words, const HeadLane &g, int c0, int C,
+                                                 float (&best)[4], int (&arg)[4]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!FULL && c0 + u >= C) break;
+        float v[4];
+        head_values(stage + (c0 + u) * plane_words, g, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            arg[e] = !(v[e] <= best[e]) ? c0 + u : arg[e];
+            best[e] = __builtin_elementwise_maximum(best[e], v[e]);   // NaN-propagating
+        }
+    }
+}
+
 // Source rows of one tile: where they lie, and the split of a chunk number (16 bytes = 8 halves of one
 // class's rows) into class, row and chunk of the row.
 struct HeadRows {
@@ -927,7 +944,8 @@ struct HeadRows {
 
 // NCH = 16-byte source chunks a thread stages per tile at most (the host picks 4 or 8 by the stage's size).
 // PROBS: the teacher comes as prepared probabilities and per-pixel entropy term (kd_teacher_prepare_kernel).
-template <int U, int NCH, bool PROBS>
+// LOSS = false: no teacher and no loss, only the arg-max histogram of the interpolated logits (evaluation loops).
+template <int U, int NCH, bool PROBS, bool LOSS = true>
 __global__ __launch_bounds__(kKdThreads, 2) void kdlite_head_kernel(HeadArgs h) {   // two waves per SIMD at least
     extern __shared__ float4 head_lds_raw[];
     const KdArgs &a = h.kd;
@@ -1032,7 +1050,7 @@ __global__ __launch_bounds__(kKdThreads, 2) void kdlite_head_kernel(HeadArgs h) 
                 g.bot[e] = (y1 - y_lo) * row_words + x0;
             }
         }
-        const float *t_img = a.t + (long long)n * C * a.HW;
+        const float *t_img = LOSS ? a.t + (long long)n * C * a.HW : nullptr;
         long long lab[4];
         load_labels<4>(a.labels + (long long)n * a.HW + r, lab);
         float hn[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1052,15 +1070,21 @@ __global__ __launch_bounds__(kKdThreads, 2) void kdlite_head_kernel(HeadArgs h) 
             best[e] = -__builtin_inff();
             arg[e] = 0;
         }
+        if constexpr (LOSS) {
 #pragma unroll 1
-        for (int c0 = 0; c0 < CU; c0 += U)
-            head_fold<U, true, PROBS>(st, stage, plane_words, g, t_img, a.HW, r, c0, C, id, k2, best, arg);
-        // what is left of the class axis: a single plane as a step of its own (21 classes = 5 x 4 + 1), more as one
-        // step whose surplus planes are filled
-        if (C - CU == 1)
-            head_fold<1, true, PROBS>(st, stage, plane_words, g, t_img, a.HW, r, CU, C, id, k2, best, arg);
-        else if (CU < C)
-            head_fold<U, false, PROBS>(st, stage, plane_words, g, t_img, a.HW, r, CU, C, id, k2, best, arg);
+            for (int c0 = 0; c0 < CU; c0 += U)
+                head_fold<U, true, PROBS>(st, stage, plane_words, g, t_img, a.HW, r, c0, C, id, k2, best, arg);
+            // what is left of the class axis: a single plane as a step of its own (21 classes = 5 x 4 + 1), more as
+            // one step whose surplus planes are filled
+            if (C - CU == 1)
+                head_fold<1, true, PROBS>(st, stage, plane_words, g, t_img, a.HW, r, CU, C, id, k2, best, arg);
+            else if (CU < C)
+                head_fold<U, false, PROBS>(st, stage, plane_words, g, t_img, a.HW, r, CU, C, id, k2, best, arg);
+        } else {
+#pragma unroll 1
+            for (int c0 = 0; c0 < CU; c0 += U) head_fold_argmax<U, true>(stage, plane_words, g, c0, C, best, arg);
+            if (CU < C) head_fold_argmax<U, false>(stage, plane_words, g, CU, C, best, arg);
+        }
 
         if ((best[0] != best[0]) | (best[1] != best[1]) | (best[2] != best[2]) | (best[3] != best[3])) {
             // a NaN among a pixel's logits: the exact class-by-class walk
@@ -1078,6 +1102,12 @@ __global__ __launch_bounds__(kKdThreads, 2) void kdlite_head_kernel(HeadArgs h) 
                     arg[e] = take ? c : arg[e];
                 }
             }
+        }
+        if constexpr (!LOSS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (lab[e] >= 0 && lab[e] < C) atomicAdd(&hist[(int)lab[e] * C + arg[e]], 1u);
+            continue;
         }
         float p_kl = 0.f, p_nv = 0.f, p_ce = 0.f, p_w = 0.f;
 #pragma unroll
@@ -1102,8 +1132,9 @@ __global__ __launch_bounds__(kKdThreads, 2) void kdlite_head_kernel(HeadArgs h) 
         acc[2] += p_ce;
         acc[3] += p_w;
     }
-    if (bad) atomicAdd(reinterpret_cast<unsigned long long *>(a.bad), (unsigned long long)bad);
+    if (LOSS && bad) atomicAdd(reinterpret_cast<unsigned long long *>(a.bad), (unsigned long long)bad);
     conf_finish<kKdThreads>(lds_hist, h.copies, h.stride, C * C, 0u, h.tail);
+    if constexpr (!LOSS) return;
     double out8[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) out8[k] = k < 4 ? acc[k % 4] : 0.0;
@@ -1316,29 +1347,26 @@ extern "C" int spice_kd_teacher_prepare(const float *teacher, int64_t n, int64_t
     return SPICE_OK;
 }
 
-extern "C" int spice_sweep_head_f16(const void *low, const float *teacher, const float *teacher_hneg,
-                                    const int64_t *labels, int64_t n, int64_t c, int64_t in_h, int64_t in_w, int64_t h, int64_t w,
-                                    int32_t align_corners, float scale_h, float scale_w,
-                                    const spice_kdlite_params *params, float *out3, int64_t *conf,
-                                    void *kd_workspace, size_t kd_workspace_bytes, void *conf_workspace,
-                                    size_t conf_workspace_bytes, void *stream) {
-    if (!params || !out3 || !conf || !kd_workspace || !conf_workspace || !low || !teacher || !labels) return SPICE_ERR_ARG;
+namespace spice {
+
+// Geometry, LDS stage and grid shared by the head kernel's entry points.  `params` and the loss workspace are
+// absent for the arg-max-only form.  Returns SPICE_OK with `ha`, `blocks`, `lds_bytes` and `chunks` set.
+static int head_prepare(HeadArgs &ha, const void *low, const int64_t *labels, int64_t n, int64_t c, int64_t in_h,
+                        int64_t in_w, int64_t h, int64_t w, int32_t align_corners, float scale_h, float scale_w,
+                        int64_t *conf, void *conf_workspace, size_t conf_workspace_bytes, int64_t &blocks,
+                        size_t &lds_bytes, int64_t &chunks) {
+    if (!conf || !conf_workspace || !low || !labels) return SPICE_ERR_ARG;
     if (n < 1 || c < 1 || h < 1 || w < 1 || in_h < 1 || in_w < 1) return SPICE_ERR_ARG;
-    if (!(params->temperature > 0.f)) return SPICE_ERR_ARG;
-    if (kd_workspace_bytes < kKdWorkspace) return SPICE_ERR_WORKSPACE;
-    if (!aligned16(kd_workspace) || !aligned16(conf_workspace) || !aligned8(conf)) return SPICE_ERR_ARG;
-    // what this kernel does not cover is left to the three separate launches
-    if (params->boundary_weight > 1.0f || params->confidence_weight != 0) return SPICE_ERR_UNSUPPORTED;
+    if (!aligned16(conf_workspace) || !aligned8(conf)) return SPICE_ERR_ARG;
     if (c > 1024 || c * c > kConfLdsBins || h > INT32_MAX || w > INT32_MAX || in_h > h || in_w > w) return SPICE_ERR_UNSUPPORTED;
     const int64_t hw = h * w;
     if (hw > INT32_MAX - 4096 || n > kConfMaxPixels / hw) return SPICE_ERR_UNSUPPORTED;
     if (w % 4 != 0 || in_w % 8 != 0) return SPICE_ERR_UNSUPPORTED;   // a lane's four pixels lie in one row; 16-byte source chunks
-    if (!aligned16(low) || !aligned16(teacher) || !aligned16(labels) || !aligned16(teacher_hneg)) return SPICE_ERR_UNSUPPORTED;
+    if (!aligned16(low) || !aligned16(labels)) return SPICE_ERR_UNSUPPORTED;
     if (conf_workspace_bytes < spice_confusion_workspace_bytes(n * hw, (int32_t)c)) return SPICE_ERR_WORKSPACE;
 
-    HeadArgs ha;
     ha.low = static_cast<const __half *>(low);
-    ha.hneg = teacher_hneg;
+    ha.hneg = nullptr;
     ha.in_h = (int)in_h;
     ha.in_w = (int)in_w;
     ha.align_corners = align_corners ? 1 : 0;
@@ -1362,36 +1390,65 @@ extern "C" int spice_sweep_head_f16(const void *low, const float *teacher, const
     ha.copies = g.copies;
     ha.stride = g.stride;
     const size_t stage_bytes = (size_t)c * lds_rows * (in_w + 1) * sizeof(float);
-    const size_t lds_bytes = stage_bytes + (size_t)g.copies * g.stride * 4;
+    lds_bytes = stage_bytes + (size_t)g.copies * g.stride * 4;
     if (lds_bytes > kHeadMaxLdsBytes) return SPICE_ERR_UNSUPPORTED;
+    chunks = c * lds_rows * (in_w / 8);   // 16-byte source chunks of a tile
+    if (chunks > 8 * kKdThreads) return SPICE_ERR_UNSUPPORTED;
 
     const int64_t tiles = n * ceil_div(hw / 4, kKdThreads);
     if (tiles > INT32_MAX) return SPICE_ERR_UNSUPPORTED;
     const long per_cu = knob_head_blocks_per_cu() >= 1 ? knob_head_blocks_per_cu() : 2;
-    int64_t blocks = tiles;
+    blocks = tiles;
     if (blocks > per_cu * device_cu_count()) blocks = per_cu * device_cu_count();
     if (blocks > kConfMaxBlocks) blocks = kConfMaxBlocks;   // also within kKdMaxBlocks
 
-    char *ws = static_cast<char *>(kd_workspace);
     KdArgs &a = ha.kd;
-    a.s = nullptr;
-    a.t = teacher;
+    a = KdArgs{};
     a.labels = reinterpret_cast<const long long *>(labels);
-    a.grad = nullptr;
-    a.class_w = params->class_weight;
-    a.upstream = nullptr;
-    a.pre_partial = reinterpret_cast<double *>(ws + kKdOffPre);
-    a.main_partial = reinterpret_cast<double *>(ws + kKdOffMain);
-    a.bad = reinterpret_cast<long long *>(ws + kKdOffBad);
-    a.ticket = reinterpret_cast<unsigned *>(ws + kKdOffTicket);
-    a.totals = reinterpret_cast<double *>(ws + kKdOffTotals);
-    a.out3 = out3;
     a.N = n;
     a.HW = hw;
     a.C = (int)c;
     a.H = (int)h;
     a.W = (int)w;
     a.pre_blocks = (int)blocks;
+    a.ignore_index = 255;
+    a.T = a.invT = 1.0f;
+    ha.tail = conf_tail(conf_workspace, conf, nullptr, (int)blocks);
+    return SPICE_OK;
+}
+
+}  // namespace spice
+
+extern "C" int spice_sweep_head_f16(const void *low, const float *teacher, const float *teacher_hneg,
+                                    const int64_t *labels, int64_t n, int64_t c, int64_t in_h, int64_t in_w, int64_t h,
+                                    int64_t w, int32_t align_corners, float scale_h, float scale_w,
+                                    const spice_kdlite_params *params, float *out3, int64_t *conf,
+                                    void *kd_workspace, size_t kd_workspace_bytes, void *conf_workspace,
+                                    size_t conf_workspace_bytes, void *stream) {
+    if (!params || !out3 || !kd_workspace || !teacher) return SPICE_ERR_ARG;
+    if (!(params->temperature > 0.f)) return SPICE_ERR_ARG;
+    if (kd_workspace_bytes < kKdWorkspace) return SPICE_ERR_WORKSPACE;
+    if (!aligned16(kd_workspace)) return SPICE_ERR_ARG;
+    // what this kernel does not cover is left to the three separate launches
+    if (params->boundary_weight > 1.0f || params->confidence_weight != 0) return SPICE_ERR_UNSUPPORTED;
+    if (!aligned16(teacher) || !aligned16(teacher_hneg)) return SPICE_ERR_UNSUPPORTED;
+    HeadArgs ha;
+    int64_t blocks = 0, chunks = 0;
+    size_t lds_bytes = 0;
+    const int rc = head_prepare(ha, low, labels, n, c, in_h, in_w, h, w, align_corners, scale_h, scale_w, conf,
+                                conf_workspace, conf_workspace_bytes, blocks, lds_bytes, chunks);
+    if (rc != SPICE_OK) return rc;
+    ha.hneg = teacher_hneg;
+    char *ws = static_cast<char *>(kd_workspace);
+    KdArgs &a = ha.kd;
+    a.t = teacher;
+    a.class_w = params->class_weight;
+    a.pre_partial = reinterpret_cast<double *>(ws + kKdOffPre);
+    a.main_partial = reinterpret_cast<double *>(ws + kKdOffMain);
+    a.bad = reinterpret_cast<long long *>(ws + kKdOffBad);
+    a.ticket = reinterpret_cast<unsigned *>(ws + kKdOffTicket);
+    a.totals = reinterpret_cast<double *>(ws + kKdOffTotals);
+    a.out3 = out3;
     a.ignore_index = params->ignore_index;
     a.T = params->temperature;
     a.invT = 1.0f / params->temperature;
@@ -1400,10 +1457,7 @@ extern "C" int spice_sweep_head_f16(const void *low, const float *teacher, const
     a.coef_ce = params->alpha;
     a.coef_kd = 1.0f - params->alpha;
     a.conf = 0;
-    ha.tail = conf_tail(conf_workspace, conf, nullptr, (int)blocks);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int64_t chunks = c * lds_rows * (in_w / 8);   // 16-byte source chunks of a tile
-    if (chunks > 8 * kKdThreads) return SPICE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)blocks), block(kKdThreads);
     const bool probs = teacher_hneg != nullptr;
     if (chunks > 4 * kKdThreads) {
@@ -1417,6 +1471,26 @@ extern "C" int spice_sweep_head_f16(const void *low, const float *teacher, const
         else
             hipLaunchKernelGGL((kdlite_head_kernel<4, 4, false>), grid, block, lds_bytes, st, ha);
     }
+    SPICE_LAUNCH_CHECK();
+    return SPICE_OK;
+}
+
+extern "C" int spice_upsample_argmax_confusion_f16(const void *low, const int64_t *labels, int64_t n, int64_t c,
+                                                   int64_t in_h, int64_t in_w, int64_t h, int64_t w,
+                                                   int32_t align_corners, float scale_h, float scale_w, int64_t *conf,
+                                                   void *conf_workspace, size_t conf_workspace_bytes, void *stream) {
+    HeadArgs ha;
+    int64_t blocks = 0, chunks = 0;
+    size_t lds_bytes = 0;
+    const int rc = head_prepare(ha, low, labels, n, c, in_h, in_w, h, w, align_corners, scale_h, scale_w, conf,
+                                conf_workspace, conf_workspace_bytes, blocks, lds_bytes, chunks);
+    if (rc != SPICE_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)blocks), block(kKdThreads);
+    if (chunks > 4 * kKdThreads)
+        hipLaunchKernelGGL((kdlite_head_kernel<4, 8, false, false>), grid, block, lds_bytes, st, ha);
+    else
+        hipLaunchKernelGGL((kdlite_head_kernel<4, 4, false, false>), grid, block, lds_bytes, st, ha);
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;
 }

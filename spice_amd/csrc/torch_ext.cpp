@@ -330,6 +330,30 @@ Tensor sweep_head(const Tensor &low, const Tensor &teacher, const c10::optional<
     return out3;
 }
 
+// Arg-max histogram of bilinearly up-sampled fp16 logits in one launch (evaluation loops).  False when the library
+// does not cover the case (nothing was launched).
+bool upsample_argmax_confusion(Tensor conf, const Tensor &low, const Tensor &labels, bool align_corners, double scale_h,
+                               double scale_w, Tensor workspace) {
+    check_dev(low, "low_logits", at::kHalf);
+    check_dev(labels, "labels", at::kLong);
+    check_dev(workspace, "workspace", at::kByte);
+    check_same_device(low, labels, "labels");
+    check_same_device(low, conf, "conf");
+    check_same_device(low, workspace, "workspace");
+    TORCH_CHECK_VALUE(low.dim() == 4 && labels.dim() == 3 && labels.size(0) == low.size(0),
+                      "low_logits must be [N,C,h,w] and labels [N,H,W]");
+    check_conf(conf, low.size(1));
+    c10::DeviceGuard guard(low.device());
+    const int rc = spice_upsample_argmax_confusion_f16(low.data_ptr(), labels.data_ptr<int64_t>(), low.size(0), low.size(1),
+                                                       low.size(2), low.size(3), labels.size(1), labels.size(2),
+                                                       align_corners ? 1 : 0, (float)scale_h, (float)scale_w,
+                                                       conf.data_ptr<int64_t>(), workspace.data_ptr(),
+                                                       (size_t)workspace.numel(), current_stream(low));
+    if (rc == SPICE_ERR_UNSUPPORTED) return false;
+    check_rc(rc, "spice_upsample_argmax_confusion_f16");
+    return true;
+}
+
 void scale_inplace(Tensor x, const Tensor &scale) {
     check_dev(x, "x", at::kFloat);
     check_dev(scale, "scale", at::kFloat);
@@ -715,6 +739,8 @@ TORCH_LIBRARY(spice, m) {
           &confusion_update);
     m.def("confusion_update_static(Tensor(a!) conf, Tensor preds, Tensor target, int num_classes, "
           "Tensor(b!)? invalid_count) -> ()", &confusion_update_static);
+    m.def("upsample_argmax_confusion(Tensor(a!) conf, Tensor low, Tensor labels, bool align_corners, float scale_h, "
+          "float scale_w, Tensor(b!) workspace) -> bool", &upsample_argmax_confusion);
     m.def("kd_teacher_prepare(Tensor teacher, float temperature) -> (Tensor, Tensor)", &kd_teacher_prepare);
     m.def("sweep_head(Tensor low, Tensor teacher, Tensor? teacher_hneg, Tensor labels, Tensor(a!) conf, bool align_corners, float scale_h, "
           "float scale_w, float temperature, float alpha, int ignore_index, Tensor? class_weight, "

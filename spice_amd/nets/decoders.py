@@ -266,3 +266,23 @@ class SegmentationModel(nn.Module):
 
     def forward(self, x):
         return self.segmentation_head(self.decoder(self.encoder(x)))
+
+    def forward_to_head(self, x):
+        """The forward up to the head's convolution, for the kernels that up-sample on the fly (the tail of a sweep
+        candidate, the arg-max histogram of an evaluation batch): (low, up) = the head convolution's fp16 output and
+        the up-sampling module still to be applied, when the head is convolution -> nn.UpsamplingBilinear2d ->
+        identity and the call is an fp16-autocast inference pass on a HIP device through the library's kernels;
+        (logits, None) if the pass turned out ordinary after all; None, without having run anything, in every other
+        situation (the caller then calls the model)."""
+        head = self.segmentation_head
+        if (not isinstance(x, torch.Tensor) or not x.is_cuda or torch.is_grad_enabled() or not layers.library_forward()
+                or not torch.is_autocast_enabled("cuda") or torch.get_autocast_dtype("cuda") != torch.float16
+                or type(self).forward is not SegmentationModel.forward
+                or not isinstance(head, nn.Sequential) or len(head) != 3 or not isinstance(head[1], BilinearUp)
+                or type(head[2]) is not nn.Identity or layers._hooked(head) or layers._hooked(head[1]) or layers._hooked(self)
+                or torch.nn.modules.module._global_forward_hooks):
+            return None
+        low = head[0](self.decoder(self.encoder(x)))
+        if low.dtype != torch.float16 or low.dim() != 4:
+            return head[1](low), None   # finished the ordinary way
+        return low.contiguous(), head[1]

@@ -288,6 +288,19 @@ def kdlite_forward(student: torch.Tensor, teacher: torch.Tensor, labels: torch.T
     return out3, grad, sums
 
 
+def upsample_argmax_confusion(conf: torch.Tensor, low: torch.Tensor, target: torch.Tensor, *,
+                              align_corners: bool = True, scale_factor: Optional[float] = None) -> bool:
+    """argmax_confusion_update(conf, upsample_bilinear(low -> target's size), target) in one launch over the small
+    fp16 logits `low` [N,C,h,w]; the full-size logits are never written.  False when the library does not cover the
+    case (nothing was launched: up-sample, then argmax_confusion_update)."""
+    if not low.is_cuda:
+        nat.require_device_tensor(low, "low_logits", torch.float16)
+    c = low.shape[1]
+    ws = _workspace("conf%d" % c, conf.device, nat.lib().spice_confusion_workspace_bytes(target.numel(), c))
+    sf = float(scale_factor) if scale_factor else 0.0
+    return bool(spice_ops().upsample_argmax_confusion(conf, low, target, bool(align_corners), sf, sf, ws))
+
+
 def kd_teacher_prepare(teacher: torch.Tensor, temperature: float) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
     """Once per teacher of a sweep: (softmax(teacher / T) over the class axis [N,C,H,W] fp32, per-pixel
     sum p ln p [N,H,W] fp32) for sweep_head(teacher=..., teacher_hneg=...); None when the library does not cover the

@@ -73,9 +73,14 @@ class CoreEvaluator:
                               model_info: Optional[Dict] = None) -> Dict[str, Any]:
         model.eval()
         fused = hasattr(metrics_calculator, "update_from_logits")
+        whole = hasattr(metrics_calculator, "update_from_model")
         with torch.no_grad():
             for batch in data_loader:
                 images, masks = self._extract_batch_data(batch)
+                if whole:   # forward, arg-max and histogram behind one call (the up-sampling inside the last launch)
+                    with torch.amp.autocast(self.device.type, enabled=(self.device.type == "cuda")):
+                        metrics_calculator.update_from_model(model, images, masks)
+                    continue
                 outputs = self._forward_pass(model, images)
                 if fused:
                     metrics_calculator.update_from_logits(outputs, masks)

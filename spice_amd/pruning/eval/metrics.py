@@ -39,6 +39,12 @@ class SegmentationMetrics:
         ops.argmax_confusion_update(self.conf, logits.contiguous(), targets.long().contiguous(),
                                     self.num_classes)
 
+    def update_from_model(self, model, images: torch.Tensor, targets: torch.Tensor):
+        """Forward + update_from_logits, inside the caller's autocast region; models that end in a bilinear
+        up-sampling are stopped at their head's convolution and up-sampled inside the histogram launch."""
+        from ...baseline.eval.metrics import update_confusion_matrix_from_model
+        update_confusion_matrix_from_model(self.conf, model, images, targets.long(), self.num_classes)
+
     def compute_metrics(self) -> Dict[str, Any]:
         bad = self._bad_count() - self._bad_base
         if bad:

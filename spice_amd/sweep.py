@@ -401,6 +401,8 @@ class SensitivitySweep:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             parts = self._forward_to_head(images) if (with_kd and self.fused_head) else None
             logits = None
+            if parts is not None and parts[1] is None:
+                logits, parts = parts[0].contiguous(), None
             if parts is not None:
                 # up-sampling, loss and arg-max histogram in one launch over the head's small fp16 output
                 low, up = parts
@@ -423,7 +425,7 @@ class SensitivitySweep:
                     if direct is None:
                         kd_out.copy_(out3)
                     self.head_launches += 1
-            else:
+            elif logits is None:
                 logits = self.forward(images).contiguous()
             if logits is not None:
                 ops.argmax_confusion_update(conf_out, logits, labels, self.num_classes)
@@ -441,23 +443,13 @@ class SensitivitySweep:
         return moved
 
     def _forward_to_head(self, images: torch.Tensor):
-        """(the head convolution's fp16 output, the up-sampling module behind it) when the network ends in
-        convolution -> nn.UpsamplingBilinear2d -> identity and runs under fp16 autocast on the library's kernels;
-        None otherwise (the caller then runs the whole forward)."""
-        from .nets import layers
-        from .nets.decoders import BilinearUp
+        """SegmentationModel.forward_to_head on the batch under this sweep's fp16 autocast: (low, up), (logits, None),
+        or None when the network cannot stop at its head's convolution (the caller then runs the whole forward)."""
         m = self.model
-        head = getattr(m, "segmentation_head", None)
-        if (self.autocast_dtype != torch.float16 or not images.is_cuda or not layers.library_forward()
-                or not isinstance(head, nn.Sequential) or len(head) != 3 or not isinstance(head[1], BilinearUp)
-                or type(head[2]) is not nn.Identity or not hasattr(m, "encoder") or not hasattr(m, "decoder")
-                or type(m).forward is not _segmentation_forward()):
+        if self.autocast_dtype != torch.float16 or not images.is_cuda or not hasattr(m, "forward_to_head"):
             return None
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-            low = head[0](m.decoder(m.encoder(self._network_input(images))))
-        if low.dtype != torch.float16 or low.dim() != 4:
-            return None
-        return low.contiguous(), head[1]
+            return m.forward_to_head(self._network_input(images))
 
     def run(self, images: torch.Tensor, labels: torch.Tensor, indices: Optional[Sequence[int]] = None,
             with_kd: bool = True) -> Dict[str, torch.Tensor]:
@@ -513,11 +505,6 @@ class SensitivitySweep:
             for tb in ([table, kd] if with_kd else [table]):
                 sdist.all_reduce_sum_(tb)
         return {"confusion": table, "kd": kd, "miou": miou_from_confusion(table)}
-
-
-def _segmentation_forward():
-    from .nets.decoders import SegmentationModel
-    return SegmentationModel.forward
 
 
 def miou_from_confusion(table: torch.Tensor) -> torch.Tensor:

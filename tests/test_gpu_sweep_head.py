@@ -299,3 +299,66 @@ def test_raw_ctypes_binding_of_the_head_entry_points(dev):
                                   ctypes.byref(params), out3.data_ptr(), conf.data_ptr(), small.data_ptr(), small.numel(),
                                   conf_ws.data_ptr(), conf_ws.numel(), stream)
     assert rc != 0 and conf.sum().item() == 0   # workspace too small
+
+
+@pytest.mark.parametrize("n,c,h,w,scale,align", CASES)
+def test_upsample_argmax_confusion_equals_two_launches(dev, n, c, h, w, scale, align):
+    """The evaluation loops' form of the kernel (no teacher, no loss): identical to up-sampling followed by the
+    fused arg-max + histogram launch, on exact ties too."""
+    low, _, lab = _inputs(13, n, c, h, w, scale)
+    low = (np.round(low.astype(np.float32)) / 2).astype(np.float16)   # many exact ties between classes
+    low[0, :, 1, 1:3] = np.nan if c > 4 else low[0, :, 1, 1:3]
+    low_d, lab_d = torch.from_numpy(low).to(dev), torch.from_numpy(lab).to(dev)
+    up = ops.upsample_bilinear(low_d, scale_factor=float(scale), align_corners=align, out_dtype=torch.float32)
+    want = torch.zeros(c, c, dtype=torch.int64, device=dev)
+    ops.argmax_confusion_update(want, up, lab_d, c)
+    conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
+    for rep in (1, 2):
+        assert ops.upsample_argmax_confusion(conf, low_d, lab_d, align_corners=align, scale_factor=float(scale))
+        assert torch.equal(conf, rep * want)
+    assert int(conf.sum()) == 2 * int(((lab >= 0) & (lab < c)).sum())
+    # declined shapes launch nothing
+    odd = torch.zeros(1, c, 3, 3, dtype=torch.float16, device=dev)
+    assert not ops.upsample_argmax_confusion(conf, odd, torch.zeros(1, 12, 12, dtype=torch.int64, device=dev),
+                                             scale_factor=4.0)
+    assert torch.equal(conf, 2 * want)
+
+
+def test_evaluation_loops_with_the_upsampling_inside_the_histogram_launch(dev):
+    """inference() and SegmentationMetrics.update_from_model on a DeepLabV3+ (head = convolution -> x4 bilinear
+    up-sampling): the same results with the up-sampling inside the histogram launch as with the model's own forward
+    followed by the fused arg-max + histogram launch."""
+    from spice_amd import nets
+    import importlib
+    inf = importlib.import_module("spice_amd.baseline.eval.inference")
+    bm = importlib.import_module("spice_amd.baseline.eval.metrics")
+    from spice_amd.pruning.eval.metrics import SegmentationMetrics
+    torch.manual_seed(5)
+    c = 5
+    model = nets.create_model("DeepLabV3Plus", "resnet50", c).to(dev).eval()
+    # 128 x 128: every convolution of the forward is one of the library's kernels, which give the same values on every
+    # call (MIOpen may pick another algorithm for the same problem on a later call)
+    loader = [(torch.randn(2, 3, 128, 128), torch.from_numpy(synth.label_map(k, 2, 128, 128, c, "blocky"))) for k in range(3)]
+    calls = []
+    real = ops.upsample_argmax_confusion
+    try:
+        ops.upsample_argmax_confusion = lambda *a, **k: calls.append(1) or real(*a, **k)
+        bm.FUSED_UPSAMPLE = True
+        got = inf.inference(model, loader, dev, num_classes=c, shard=False)
+        assert len(calls) == len(loader), "the one-launch route must have been taken"
+        sm = SegmentationMetrics(c, device=dev)
+        with torch.no_grad(), torch.amp.autocast("cuda"):
+            for x, y in loader:
+                sm.update_from_model(model, x.to(dev), y.to(dev))
+        bm.FUSED_UPSAMPLE = False
+        ref = inf.inference(model, loader, dev, num_classes=c, shard=False)
+        assert len(calls) == 2 * len(loader)
+        sm2 = SegmentationMetrics(c, device=dev)
+        with torch.no_grad(), torch.amp.autocast("cuda"):
+            for x, y in loader:
+                sm2.update_from_logits(model(x.to(dev)), y.to(dev))
+    finally:
+        ops.upsample_argmax_confusion = real
+        bm.FUSED_UPSAMPLE = True
+    assert got == ref
+    assert torch.equal(sm.conf, sm2.conf) and int(sm.conf.sum()) > 0

@@ -206,6 +206,17 @@ def main():
         report("sweep_head, teacher's softmax prepared once (one launch)", timed(fns, args.iters), nbytes + n * h * w * 4)
         del prepared
 
+        fns = [lambda a=a: ops.upsample_argmax_confusion(conf, a, lab, align_corners=True, scale_factor=4.0) for a in lows]
+        report("upsample + argmax_confusion in one launch (evaluation loops)", timed(fns, args.iters),
+               n * c * (h // 4) * (w // 4) * 2 + n * h * w * 8)
+
+        def two(a):
+            ops.argmax_confusion_update(conf, ops.upsample_bilinear(a, scale_factor=4.0, align_corners=True,
+                                                                    out_dtype=torch.float32), lab, c)
+        fns = [lambda a=a: two(a) for a in lows]
+        report("the same in two launches (up-sampling, arg-max histogram)", timed(fns, args.iters),
+               n * c * (h // 4) * (w // 4) * 2 + n * h * w * 8)
+
         def three(a, b):
             up = ops.upsample_bilinear(a, scale_factor=4.0, align_corners=True, out_dtype=torch.float32)
             ops.argmax_confusion_update(conf, up, lab, c)

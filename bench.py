@@ -193,6 +193,26 @@ def kernel_table(dev):
     row("bilinear x4 up-sampling of the head, fp16 -> fp32 logits",
         event_ms(lambda: ops.upsample_bilinear(cyc(heads), scale_factor=4.0, align_corners=True, out_dtype=torch.float32), 20),
         heads[0].numel() * (2 + 16 * 4))
+    # a sweep candidate's tail and an evaluation batch's, up-sampling done on the fly (teachers rotate: 2 x 176 MB)
+    lab = torch.randint(0, CLASSES, (BATCH, SIZE, SIZE), device=dev)
+    teach = [3.0 * torch.randn(BATCH, CLASSES, SIZE, SIZE, device=dev) for _ in range(2)]
+    head_bytes = heads[0].numel() * 2 + P * (CLASSES * 4 + 8)
+    row("head of a sweep candidate in one launch: x4 up-sampling + KD-Lite loss + arg-max/confusion (teacher as logits)",
+        event_ms(lambda: ops.sweep_head(cyc(heads), cyc(teach), lab, conf, align_corners=True, scale_factor=4.0,
+                                        temperature=4.0, alpha=0.7), 20), head_bytes)
+    prep = [ops.kd_teacher_prepare(t, 4.0) for t in teach]
+    del teach
+
+    def head_prepared():
+        pr = cyc(prep)
+        return ops.sweep_head(cyc(heads), pr[0], lab, conf, align_corners=True, scale_factor=4.0, temperature=4.0, alpha=0.7,
+                              teacher_hneg=pr[1])
+    row("the same against the teacher's softmax prepared once per sweep (the form the sweep runs)",
+        event_ms(head_prepared, 20), head_bytes + P * 4)
+    del prep
+    row("x4 up-sampling + arg-max/confusion in one launch (evaluation loops)",
+        event_ms(lambda: ops.upsample_argmax_confusion(conf, cyc(heads), lab, align_corners=True, scale_factor=4.0), 20),
+        heads[0].numel() * 2 + P * 8)
     acts = [torch.randn(BATCH, 256, SIZE // 4, SIZE // 4, device=dev).half() for _ in range(4)]
     bn = [torch.rand(256, device=dev) + 0.5 for _ in range(4)]
     row("batch-norm + residual add + ReLU, [8,256,128,128] fp16",

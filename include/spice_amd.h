@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPICE_ABI_VERSION 4
+#define SPICE_ABI_VERSION 5
 
 #define SPICE_OK 0
 #define SPICE_ERR_ARG 10001         /* null pointer, negative size, misaligned base */

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libspice_amd.so")
 TORCH_LIB_PATH = os.path.join(_HERE, "lib", "libspice_torch.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 ERR_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_BLAS, ERR_STATIC_LIMIT = 10001, 10002, 10003, 10004, 10005
 IMP_L1, IMP_L2, IMP_TAYLOR = 0, 1, 2
 

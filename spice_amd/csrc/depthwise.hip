@@ -11,7 +11,8 @@
 // HBM-bound: reads the input once (neighbouring rows and the two edge columns of a lane's window
 // come from L1/L2) and writes the output once.  A lane produces 8 consecutive outputs of one row:
 // three 16-byte row loads plus the two neighbours left and right of each, 72 multiply-adds,
-// one 16-byte store.
+// one 16-byte store.  Planes large enough take the four-rows-per-lane form further down (six row
+// loads for 32 outputs, edge columns from the neighbouring lanes' registers).
 #include "common.h"
 
 #include <hip/hip_fp16.h>
@@ -114,6 +115,76 @@ __global__ __launch_bounds__(kDwThreads) void depthwise3x3_kernel(DwArgs a) {
     if (active) *reinterpret_cast<f16x8_t *>(a.y + (static_cast<int64_t>(plane) * a.h + y) * a.wd + x0) = out;
 }
 
+// Four output rows per lane: six row loads serve 32 outputs (the one-row form above loads three rows and six edge
+// halfs for 8), and the two edge columns of a lane's window come from its neighbours' registers (the lanes of a plane
+// row sit side by side in one wave: lanes_per_row divides 64), so a lane has 96 bytes in flight from six loads and
+// nothing else to wait for.  Same sums, in the same order, as the one-row form.
+constexpr int kDwRowsPerLane = 4;
+typedef unsigned dw_u32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(kDwThreads) void depthwise3x3_rows4_kernel(DwArgs a) {
+    const int plane = blockIdx.x / a.blocks_per_plane;
+    const int band = blockIdx.x - plane * a.blocks_per_plane;
+    const int ch = plane % a.c;
+    const int ly = threadIdx.x / a.lanes_per_row;
+    const int lx = threadIdx.x - ly * a.lanes_per_row;
+    const int y0 = (band * a.rows_per_block + ly) * kDwRowsPerLane;   // rows_per_block: lane rows per workgroup
+    const bool lane_row_in = ly < a.rows_per_block;
+    const int x0 = lx * 8;
+
+    unsigned wraw[9];
+    dw_load_taps(a, ch, wraw);
+
+    const _Float16 *src = a.x + static_cast<int64_t>(plane) * a.h * a.wd;
+    // all loads first, from clamped (always valid) addresses; what lies outside the plane is zeroed after
+    dw_u32x4_t raw[kDwRowsPerLane + 2];
+#pragma unroll
+    for (int r = 0; r < kDwRowsPerLane + 2; ++r) {
+        const int yy = min(max(y0 + r - 1, 0), a.h - 1);
+        raw[r] = *reinterpret_cast<const dw_u32x4_t *>(src + static_cast<int64_t>(yy) * a.wd + x0);
+    }
+    float v[kDwRowsPerLane + 2][10];
+#pragma unroll
+    for (int r = 0; r < kDwRowsPerLane + 2; ++r) {
+        const int yy = y0 + r - 1;
+        const bool row_in = yy >= 0 && yy < a.h;
+        // the neighbours' last and first column (every lane of the wave takes part; a row's first and last lane
+        // get their own value back and are zeroed: the plane's edge)
+        const unsigned lw = __shfl_up(raw[r].w, 1, a.lanes_per_row);
+        const unsigned rw = __shfl_down(raw[r].x, 1, a.lanes_per_row);
+        const _Float16 left = __builtin_bit_cast(_Float16, static_cast<unsigned short>(lw >> 16));
+        const _Float16 right = __builtin_bit_cast(_Float16, static_cast<unsigned short>(rw & 0xffffu));
+        const f16x8_t mid = __builtin_bit_cast(f16x8_t, raw[r]);
+        v[r][0] = row_in && lx > 0 ? static_cast<float>(left) : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[r][e + 1] = row_in ? static_cast<float>(mid[e]) : 0.0f;
+        v[r][9] = row_in && lx + 1 < a.lanes_per_row ? static_cast<float>(right) : 0.0f;
+    }
+    float wt[9];
+    dw_taps_to_float(a, wraw, wt);
+#pragma unroll
+    for (int k = 0; k < kDwRowsPerLane; ++k) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)   // tap order: rows first, left to right (a tap outside the plane adds w * 0)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(wt[r * 3 + j], v[k + r][e + j], acc[e]);
+        f16x8_t out;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float o = acc[e];
+            asm volatile("" : "+v"(o));   // fp32 sum first, conversion as a step of its own
+            out[e] = static_cast<_Float16>(o);
+        }
+        if (lane_row_in && y0 + k < a.h)
+            *reinterpret_cast<f16x8_t *>(a.y + (static_cast<int64_t>(plane) * a.h + y0 + k) * a.wd + x0) = out;
+    }
+}
+
 // Dilated variant (dilation a multiple of 4, padding = dilation): the three depthwise branches of the
 // ASPP block (dilation 12 / 24 / 36 on 32x32 planes).  torch runs these on its own depthwise kernel,
 // which accumulates the nine products in fp32 in tap order (row by row, left to right); so does this
@@ -200,6 +271,8 @@ __global__ __launch_bounds__(kDwThreads) void depthwise3x3_dilated_kernel(DwArgs
 
 }  // namespace spice
 
+SPICE_ENV_KNOB(knob_dw_rows4, "SPICE_DW_ROWS4", 1)   // 0: always one output row per lane (A/B measurements)
+
 static int spice_depthwise_common(const void *x, const void *weight, int32_t weight_dtype, void *y, int64_t n,
                                   int64_t c, int32_t h, int32_t w, int32_t dilation, void *stream);
 
@@ -238,7 +311,15 @@ static int spice_depthwise_common(const void *x, const void *weight, int32_t wei
     a.w_is_f32 = weight_dtype == 0;
     const int64_t blocks = n * c * a.blocks_per_plane;
     if (blocks > INT32_MAX) return SPICE_ERR_UNSUPPORTED;
-    if (dilation == 1)
+    const int lane_rows = static_cast<int>(ceil_div(h, kDwRowsPerLane));   // rows of lanes a plane needs at four rows per lane
+    if (dilation == 1 && knob_dw_rows4() != 0 && 64 % a.lanes_per_row == 0 && lane_rows * a.lanes_per_row >= kDwThreads / 2) {
+        // four rows per lane where a plane keeps at least half a workgroup busy that way
+        a.rows_per_block = kDwThreads / a.lanes_per_row;
+        if (a.rows_per_block > lane_rows) a.rows_per_block = lane_rows;
+        a.blocks_per_plane = static_cast<int>(ceil_div(lane_rows, a.rows_per_block));
+        hipLaunchKernelGGL(depthwise3x3_rows4_kernel, dim3(static_cast<unsigned>(n * c * a.blocks_per_plane)),
+                           dim3(kDwThreads), 0, static_cast<hipStream_t>(stream), a);
+    } else if (dilation == 1)
         hipLaunchKernelGGL(depthwise3x3_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kDwThreads), 0,
                            static_cast<hipStream_t>(stream), a);
     else {

@@ -581,7 +581,11 @@ def test_model_forward_on_library_kernels_equals_torch_forward(dev):
 
 @pytest.mark.parametrize("shape,w_dtype", [((2, 6, 8, 8), torch.float16), ((1, 3, 5, 16), torch.float32),
                                             ((2, 304, 36, 40), torch.float32), ((8, 304, 128, 128), torch.float32),
-                                            ((1, 2, 1, 8), torch.float16), ((2, 5, 300, 24), torch.float16)])
+                                            ((1, 2, 1, 8), torch.float16), ((2, 5, 300, 24), torch.float16),
+                                            # four output rows per lane: a height that is no multiple of four, rows of
+                                            # 8 / 16 / 32 / 64 lanes, a last workgroup that is partly outside the plane
+                                            ((1, 3, 130, 128), torch.float16), ((2, 4, 37, 512), torch.float32),
+                                            ((1, 2, 257, 64), torch.float16), ((3, 7, 16, 256), torch.float32)])
 def test_depthwise_conv3x3_vs_oracle_and_torch(dev, shape, w_dtype):
     """Bit for bit against the CPU oracle of torch's own depthwise kernel (fp32 sums in tap order, one rounding)
     and against that kernel itself on the device (torch with MIOpen switched off); within one fp16 step of the

@@ -544,12 +544,12 @@ def main():
         prepared = sweep._teacher_prepared is not None   # teacher's softmax taken once per sweep: + 4 bytes per pixel
         kd_bytes = (BATCH * CLASSES * (SIZE // 4) * (SIZE // 4) * 2 + BATCH * SIZE * SIZE * (CLASSES * 4 + 8)
                     + (BATCH * SIZE * SIZE * 4 if prepared else 0))
-        kd_kernel = (f"spice::kdlite_head_kernel<4,4,{str(prepared).lower()}> (one launch per candidate: bilinear "
+        kd_kernel = (f"spice::kdlite_head_kernel<4,4,{str(prepared).lower()},true> (one launch per candidate: bilinear "
                      "up-sampling of the head's fp16 logits + KD-Lite loss + arg-max + confusion histogram"
                      + (", against the teacher's probabilities prepared once per sweep" if prepared else "") +
                      "; replaces upsample_bilinear_kernel, argmax_confusion_kernel and kdlite_main_kernel = 128 us "
                      "and 550 MB of traffic per candidate)")
-        kd_key = f"spice::kdlite_head_kernel<4, 4, {str(prepared).lower()}>"
+        kd_key = f"spice::kdlite_head_kernel<4, 4, {str(prepared).lower()}, true>"
         kd_note = ("bound by vector arithmetic, not by memory: " + ("two" if prepared else "three") + " exponentials "
                    "(quarter rate) and the six-operation interpolation per logit; the loss kernel alone on full-size "
                    "logits reaches 0.71 (`kernels` table)")

@@ -4,15 +4,22 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Either invocation works: started as a plain process with --gpus N > 1 (no WORLD_SIZE in the environment), this
+file starts the N ranks itself - `python -m torch.distributed.run ... bench.py <same arguments>` as a CHILD process,
+before anything here has imported torch or touched a GPU - lets rank 0's JSON line through and exits with the
+child's status.
+
 Workload: the magnitude_taylor sensitivity sweep of DeepLabV3Plus_resnet on one synthetic
 21-class 8x3x512x512 evaluation batch.  One step = one sweep candidate per rank: slice one channel
-group at one ratio (HIP gather), forward the sliced network (MIOpen, fp16 autocast as the
-reference's evaluator), accumulate its mIoU confusion matrix (HIP fused arg-max histogram) and its
-KD-Lite loss against the un-pruned network's logits (HIP fused loss).  Weak scaling: every rank
-evaluates K candidates of its cost-balanced share; the per-candidate tables are combined with one
-all-reduce inside the timed region.  Set-up outside the timed region: model build, the Taylor
-calibration pass (HIP Taylor reduction) with quota allocation, group magnitude importance (HIP),
-launch plans.  Rank 0 prints ONE JSON line.
+group at one ratio (HIP gather), forward the sliced network from the first block the group touches
+(fp16 autocast as the reference's evaluator; every convolution on the library's kernels; the
+activations of the un-pruned network in front of that block come from the teacher forward of the
+same sweep), and ONE launch for the head's up-sampling, the mIoU confusion matrix (arg-max
+histogram) and the KD-Lite loss against the un-pruned network's logits.  Weak scaling: every rank
+evaluates K candidates spread evenly over its cost-balanced share; the per-candidate tables are
+combined with one all-reduce inside the timed region.  Set-up outside the timed region: model build,
+the Taylor calibration pass (HIP Taylor reduction) with quota allocation, group magnitude importance
+(HIP), launch plans of the warm-up candidates.  Rank 0 prints ONE JSON line.
 
     python bench.py --gpus N --strong
 times the WHOLE sweep instead (strong scaling: the 414 candidates are fixed, ranks share them):
@@ -29,10 +36,41 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def launch_ranks_if_needed(argv=None) -> None:
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks as a child
+    `python -m torch.distributed.run` of this same file and exit with its status.  Runs before torch or the
+    package is imported, so this process never initialises a GPU (it only waits for the child; the child is a
+    new process, not an exec of this one).  Returns when the process is itself a rank, or N == 1."""
+    argv = sys.argv[1:] if argv is None else list(argv)
+    probe = argparse.ArgumentParser(add_help=False)
+    probe.add_argument("--gpus", type=int, default=1)
+    known, _ = probe.parse_known_args(argv)
+    if known.gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as s:   # a free rendezvous port on the loop-back interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={known.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between the ranks' processes
+    # torchrun gives every rank ONE host thread unless told otherwise; the ranks share the host's cores instead
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // known.gpus)))
+    print(f"[bench] starting {known.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+if __name__ == "__main__":
+    launch_ranks_if_needed()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
 sys.path.insert(0, ROOT)
 
 from spice_amd import _native as nat  # noqa: E402
@@ -103,15 +141,60 @@ def pmc_traffic(kernel_key):
     return None, None
 
 
-def kernel_table(dev):
-    """HIP-event time of every hand-written kernel at the benchmark sizes, cycling through more
-    than 256 MiB of distinct buffers so the Infinity Cache cannot serve repeats."""
-    out = []
+def cpu_description():
+    """(threads the CPU legs use, what the host is): the box's share of host cores is what OMP_NUM_THREADS says
+    where it is set (os.cpu_count() names every core of the machine, many times the share of a one-GPU box)."""
+    n_os = os.cpu_count() or 1
+    try:
+        share = int(os.environ.get("OMP_NUM_THREADS", "0"))
+    except ValueError:
+        share = 0
+    threads = min(n_os, share) if share > 0 else n_os
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return threads, {"cpu_model": model, "os_cpu_count": n_os, "threads_used": threads,
+                     "threads_from": "OMP_NUM_THREADS" if share > 0 else "os.cpu_count()"}
 
-    def row(name, ms, nbytes):
+
+def cpu_min_ms(fn, reps=3):
+    """min-of-`reps` wall-clock of a CPU leg, in ms (one untimed call first: allocator and thread pool)."""
+    fn()
+    best = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        best = min(best, time.perf_counter() - t0)
+    return 1e3 * best
+
+
+def kernel_table(dev, cpu_legs=True):
+    """HIP-event time of every hand-written kernel at the benchmark sizes, cycling through more
+    than 256 MiB of distinct buffers so the Infinity Cache cannot serve repeats.  The four path functions also
+    carry `cpu_ms`: the reference's torch op sequence for that function (the oracle's restatement of it) on the
+    same inputs copied to the host, min of 3, on the host cores of the same box."""
+    out = []
+    threads, _ = cpu_description()
+    if cpu_legs:
+        from oracle import confusion as oc
+        from oracle import importance as oi
+        from oracle import kdlite as ok
+        from oracle import selection as osel
+        torch.set_num_threads(threads)
+
+    def row(name, ms, nbytes, cpu_ms=None, cpu_what=None):
         gbs = nbytes / ms / 1e6
         out.append({"kernel": name, "ms": round(ms, 4), "algorithmic_MB": round(nbytes / 1e6, 1),
                     "GBps": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBPS, 3)})
+        if cpu_ms is not None:
+            out[-1].update({"cpu_ms": round(cpu_ms, 2), "cpu_GBps": round(nbytes / cpu_ms / 1e6, 2), "cpu_threads": threads,
+                            "cpu_leg": cpu_what, "gpu_over_cpu": round(cpu_ms / ms, 1)})
 
     def row_flops(name, ms, macs, nbytes):
         tf = 2 * macs / ms / 1e9
@@ -138,12 +221,26 @@ def kernel_table(dev):
         k[0] += 1
         return lst[k[0] % len(lst)]
 
+    cpu_w = cpu_g = None
+    if cpu_legs:   # the same values, as the per-layer tensors the reference's loop walks
+        wh, gh = ws[0].cpu(), gs[0].cpu()
+        cpu_w = [wh[off: off + o * i * kh * kw].view(o, i, kh, kw) for (o, i, kh, kw), off in zip(shapes, offs)]
+        cpu_g = [gh[off: off + o * i * kh * kw].view(o, i, kh, kw) for (o, i, kh, kw), off in zip(shapes, offs)]
+        cpu_scores = [torch.zeros(o) for o, _, _, _ in shapes]
+
+        def cpu_taylor():
+            for w_, g_, sc in zip(cpu_w, cpu_g, cpu_scores):
+                sc += oi.taylor_rows(w_, g_)
     row("importance_rows<L2> (DeepLabV3+-R50 conv weights)",
         event_ms(lambda: plan.run([cyc(ws)], (), score, nat.IMP_L2, False), 20),
-        plan.algorithmic_bytes(nat.IMP_L2))
+        plan.algorithmic_bytes(nat.IMP_L2),
+        cpu_min_ms(lambda: [oi.magnitude_rows(w_, 2) for w_ in cpu_w]) if cpu_legs else None,
+        "w.flatten(1).abs().pow(2).sum(1) per layer (torch-pruning's magnitude form)")
     row("importance_rows<TAYLOR> (weights + grads, accumulate)",
         event_ms(lambda: plan.run([cyc(ws)], [gs[k[0] % 4]], score, nat.IMP_TAYLOR, True), 20),
-        plan.algorithmic_bytes(nat.IMP_TAYLOR))
+        plan.algorithmic_bytes(nat.IMP_TAYLOR),
+        cpu_min_ms(cpu_taylor) if cpu_legs else None,
+        "scores += (grad.abs() * weight.abs()).sum((1,2,3)) per layer, pruning/sensitivity_utils.py:61-66")
     specs, idx, dpos, ipos = [], [], 0, 0
     for (o, i, kh, kw), off in zip(shapes, offs):
         ko = np.arange(0, o, 2, dtype=np.int64)
@@ -156,16 +253,25 @@ def kernel_table(dev):
     dsts = [torch.empty(dpos, device=dev) for _ in range(4)]
     row("gather (keep every 2nd out-channel of every conv)",
         event_ms(lambda: gplan.run([cyc(ws)], dsts[k[0] % 4], idx_t), 20),
-        gplan.algorithmic_bytes())
-    del ws, gs, dsts
+        gplan.algorithmic_bytes(),
+        cpu_min_ms(lambda: [osel.slice_tensor(w_, ko, None) for w_, ko in zip(cpu_w, idx)]) if cpu_legs else None,
+        "index_select(weight, 0, keep).contiguous() per layer (torch-pruning's slicing)")
+    del ws, gs, dsts, cpu_w, cpu_g
 
     sets = []
     for j in range(2):
         s = 3.0 * torch.randn(BATCH, CLASSES, SIZE, SIZE, device=dev)
         sets.append((s, s + torch.randn_like(s), torch.randint(0, CLASSES, (BATCH, SIZE, SIZE), device=dev)))
     P = BATCH * SIZE * SIZE
+    cpu_kd = None
+    if cpu_legs:
+        hs, ht, hl = (x.cpu() for x in sets[0])
+        with torch.no_grad():
+            cpu_kd = cpu_min_ms(lambda: ok.kdlite_loss(hs, ht, hl, temperature=4.0, alpha=0.7, num_classes=CLASSES))
+        del hs, ht, hl
     row("kdlite forward (T=4, alpha=0.7)",
-        event_ms(lambda: ops.kdlite_forward(*cyc(sets), temperature=4.0, alpha=0.7), 20), P * (2 * CLASSES * 4 + 8))
+        event_ms(lambda: ops.kdlite_forward(*cyc(sets), temperature=4.0, alpha=0.7), 20), P * (2 * CLASSES * 4 + 8),
+        cpu_kd, "KDLiteLoss.forward op sequence, pruning/losses.py:127-162")
     row("kdlite forward+grad (label pre-pass + fused pass)",
         event_ms(lambda: ops.kdlite_forward(*cyc(sets), temperature=4.0, alpha=0.7, want_grad=True), 10, batch=4),
         P * (3 * CLASSES * 4 + 8))
@@ -176,17 +282,42 @@ def kernel_table(dev):
         P * (CLASSES * 2 + 8))
     del lg16
     small = [(torch.randint(0, CLASSES, (P,), device=dev), torch.randint(0, CLASSES, (P,), device=dev)) for _ in range(10)]
+    cpu_cf = None
+    if cpu_legs:
+        hp, ht = small[0][0].cpu(), small[0][1].cpu()
+        hc = torch.zeros(CLASSES, CLASSES, dtype=torch.int64)
+        cpu_cf = cpu_min_ms(lambda: oc.update_confusion_torch(hc, hp, ht, CLASSES))
     row("confusion [8,512,512] int64, 21 classes",
-        event_ms(lambda: ops.confusion_update(conf, *cyc(small), CLASSES), 20), P * 16)
+        event_ms(lambda: ops.confusion_update(conf, *cyc(small), CLASSES), 20), P * 16,
+        cpu_cf, "update_confusion_matrix op sequence, baseline/eval/metrics.py:8-19")
     del small, sets
     P5 = 32 * 1024 * 2048
     t5 = torch.randint(0, 19, (P5,), device=dev)
     t5[torch.rand(P5, device=dev) < 0.1] = 255
     p5 = torch.randint(0, 19, (P5,), device=dev)
     conf5 = torch.zeros(19, 19, dtype=torch.int64, device=dev)
+    cpu_cf5 = None
+    if cpu_legs:
+        hp, ht = p5.cpu(), t5.cpu()
+        hc = torch.zeros(19, 19, dtype=torch.int64)
+        cpu_cf5 = cpu_min_ms(lambda: oc.update_confusion_torch(hc, hp, ht, 19))
+        del hp, ht
     row("confusion [32,1024,2048] int64, 19 classes",
-        event_ms(lambda: ops.confusion_update(conf5, p5, t5, 19), 10, batch=4), P5 * 16)
-    del t5, p5
+        event_ms(lambda: ops.confusion_update(conf5, p5, t5, 19), 10, batch=4), P5 * 16,
+        cpu_cf5, "update_confusion_matrix op sequence, baseline/eval/metrics.py:8-19")
+    # the evaluation loops' fused entry points at the same size: arg-max over [32,19,1024,2048] logits inside the
+    # histogram launch (fp16: 2.5 GB, past 2^31 bytes), and the x4 up-sampling of [32,19,256,512] on the fly
+    for dt, nm in ((torch.float16, "fp16"), (torch.float32, "fp32")):
+        lg5 = torch.randn(32, 19, 1024, 2048, device=dev, dtype=dt)
+        row(f"argmax+confusion {nm} logits [32,19,1024,2048]",
+            event_ms(lambda: ops.argmax_confusion_update(conf5, lg5, t5.view(32, 1024, 2048), 19), 5, warmup=2, batch=2),
+            P5 * (19 * lg5.element_size() + 8))
+        del lg5
+    low5 = torch.randn(32, 19, 256, 512, device=dev).half()
+    row("x4 up-sampling + arg-max/confusion in one launch, [32,19,256,512] -> 1024x2048",
+        event_ms(lambda: ops.upsample_argmax_confusion(conf5, low5, t5.view(32, 1024, 2048), align_corners=True, scale_factor=4.0),
+                 5, warmup=2, batch=2), low5.numel() * 2 + P5 * 8)
+    del t5, p5, low5
     # the forward-side kernels at the shapes they meet in this workload (results dropped at once: the caching
     # allocator hands the same few output buffers round, the inputs rotate)
     heads = [torch.randn(BATCH, CLASSES, SIZE // 4, SIZE // 4, device=dev).half() for _ in range(3)]
@@ -288,9 +419,11 @@ def forward_probe(sweep, candidates, images, labels, teacher, table, kd):
                         "(event pairs add gaps between launches, not to them)"}
 
 
-def cpu_candidate_baseline(model, sweep, images, labels):
-    """One sweep candidate through the CPU oracle on the host cores: group magnitude importance,
-    stable selection, index_select slicing, fp32 forward, arg-max, confusion, KD-Lite loss."""
+def cpu_candidate_baseline(model, sweep, images, labels, ignored):
+    """One sweep candidate through the CPU oracle on the host cores, min of 3: group magnitude importance,
+    stable selection, index_select slicing, fp32 forward, arg-max, confusion, KD-Lite loss.  Beside the time: how
+    far the HIP path's results for the same candidate are from the oracle's, with the fp32 forward and with the
+    fp16 forward the benchmark runs."""
     import copy
 
     from oracle import confusion as oc
@@ -298,32 +431,56 @@ def cpu_candidate_baseline(model, sweep, images, labels):
     from oracle import prune_ref
     from oracle import selection as osel
     from spice_amd.engine.depgraph import build_groups
+    from spice_amd.sweep import miou_from_confusion
 
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
-    cpu_model = copy.deepcopy(model).cpu().float().eval()
+    threads, host = cpu_description()
+    torch.set_num_threads(threads)
+    base = copy.deepcopy(model).cpu().float().eval()
     x, y = images.cpu(), labels.cpu()
     with torch.no_grad():
-        teacher = cpu_model(x)
+        teacher = base(x)
     cand = sweep.candidates[len(sweep.candidates) // 2]
     root_name = sweep.groups[cand.group].root_name
-    groups = build_groups(cpu_model)
-    g = [gg for gg in groups if gg.root_name == root_name][0]
-    t0 = time.perf_counter()
-    imp = prune_ref.group_importance(g, 2)
-    pruned = osel.select_local(imp, len(cand.pruned))
-    prune_ref.prune_group(g, pruned)
-    with torch.no_grad():
-        logits = cpu_model(x)
-    conf = np.zeros((CLASSES, CLASSES), dtype=np.int64)
-    oc.update_confusion(conf, oc.argmax_first(logits.numpy()), y.numpy(), CLASSES)
-    ok.kdlite_loss(logits, teacher, y, temperature=4.0, alpha=0.7, num_classes=CLASSES)
-    dt = time.perf_counter() - t0
+    times, conf, loss, pruned = [], None, None, None
+    for _ in range(3):
+        cpu_model = copy.deepcopy(base)
+        g = [gg for gg in build_groups(cpu_model) if gg.root_name == root_name][0]
+        t0 = time.perf_counter()
+        imp = prune_ref.group_importance(g, 2)
+        pruned = osel.select_local(imp, len(cand.pruned))
+        prune_ref.prune_group(g, pruned)
+        with torch.no_grad():
+            logits = cpu_model(x)
+        conf = np.zeros((CLASSES, CLASSES), dtype=np.int64)
+        oc.update_confusion(conf, oc.argmax_first(logits.numpy()), y.numpy(), CLASSES)
+        loss = ok.kdlite_loss(logits, teacher, y, temperature=4.0, alpha=0.7, num_classes=CLASSES)
+        times.append(time.perf_counter() - t0)
+        del cpu_model, logits
+    dt = min(times)
     same = bool(np.array_equal(pruned, cand.pruned))
-    return {"value": round(1.0 / dt, 4), "unit": "candidates/s", "cores": cores, "kind": "port",
-            "sample": f"1 candidate (group {root_name}, ratio {cand.ratio}) on the same 8x3x512x512 batch: "
-                      f"oracle importance+selection+index_select slicing, fp32 torch-CPU forward, arg-max, "
-                      f"confusion, KD-Lite loss; {dt:.2f} s; selected channels equal to the HIP path: {same}"}
+    miou_cpu = oc.metrics_from_confusion(torch.from_numpy(conf))[2]
+
+    def hip_candidate(autocast_dtype):
+        sw = sweep if autocast_dtype is not None else SensitivitySweep(
+            model, CLASSES, DEFAULT_RATIOS, ignored_layers=ignored, autocast_dtype=None)
+        r = sw.run(images, labels, indices=[cand.index])
+        cf = r["confusion"][cand.index]
+        return cf.cpu().numpy(), float(miou_from_confusion(cf).item()), [float(v) for v in r["kd"][cand.index].cpu()]
+
+    deltas = {}
+    for name, dt_ in (("hip_fp32_forward", None), ("hip_fp16_forward", torch.float16)):
+        cf, miou, kd3 = hip_candidate(dt_)
+        deltas[name] = {"pixels_in_other_cell": int(np.abs(cf - conf).sum()) // 2, "abs_d_miou": abs(miou - miou_cpu),
+                        "rel_d_loss_total": abs(kd3[0] - float(loss["total"])) / max(abs(float(loss["total"])), 1e-12),
+                        "rel_d_loss_ce": abs(kd3[1] - float(loss["ce"])) / max(abs(float(loss["ce"])), 1e-12),
+                        "abs_d_loss_kd": abs(kd3[2] - float(loss["kd"]))}
+    return {"value": round(1.0 / dt, 4), "unit": "candidates/s", "cores": threads, "kind": "port", **host,
+            "seconds_min_of_3": round(dt, 3), "seconds_all": [round(t, 3) for t in times],
+            "selected_channels_equal": same, "valid_pixels": int(conf.sum()), "miou_cpu": miou_cpu,
+            "hip_vs_cpu": deltas,
+            "sample": f"1 candidate (group {root_name}, ratio {cand.ratio}) on the same 8x3x512x512 batch, 3 times, minimum: "
+                      f"oracle importance+selection+index_select slicing, fp32 torch-CPU forward of the whole sliced network, "
+                      f"arg-max, confusion, KD-Lite loss; {dt:.2f} s on {threads} threads"}
 
 
 def whole_sweep(sweep, images, labels, dev, rank, world):
@@ -361,12 +518,15 @@ def whole_sweep(sweep, images, labels, dev, rank, world):
     }
 
 
+FORWARD_DTYPE = "f16 forward (f32 accumulation), f32 loss and importance, int64 confusion"
+FORWARD_DTYPE_FP32 = "f32 forward, f32 loss and importance, int64 confusion"
 STRONG_WORKLOAD = ("DeepLabV3Plus_resnet magnitude_taylor sensitivity sweep, ALL candidates: geometry pass + cost model + "
-                   "partition + launch plans + solver lookups + teacher forward + every candidate (gather, forward, "
-                   "arg-max/confusion, KD-Lite loss) + all-reduce of the tables")
+                   "partition + launch plans + solver lookups + teacher forward + every candidate (gather, forward from the "
+                   "first block its group touches, arg-max/confusion, KD-Lite loss) + all-reduce of the tables")
 
 
-def strong_mode(args, sweep, images, labels, dev, rank, world, tune_s, taylor_s, build_s, first_s, lanes=1, lanes_s=0.0):
+def strong_mode(args, sweep, images, labels, dev, rank, world, tune_s, taylor_s, build_s, first_s, lanes=1, lanes_s=0.0,
+                dist_info=None):
     """The whole sweep, wall-clock, max over ranks; rank 0 prints the JSON line."""
     w = whole_sweep(sweep, images, labels, dev, rank, world)
     result = {
@@ -375,7 +535,7 @@ def strong_mode(args, sweep, images, labels, dev, rank, world, tune_s, taylor_s,
         "n_gpus": world, "steps": w["candidates"], "warmup": 0,
         "ms_per_step": round(1e3 * w["sweep_s"] / w["candidates"], 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": FORWARD_DTYPE_FP32 if args.fp32_forward else FORWARD_DTYPE, "data": "synthetic",
         "config": {"workload": STRONG_WORKLOAD,
                    "num_classes": CLASSES, "eval_batch": [BATCH, 3, SIZE, SIZE], "candidates": w["candidates"],
                    "groups": len(sweep.groups), "ratios": list(DEFAULT_RATIOS),
@@ -388,11 +548,34 @@ def strong_mode(args, sweep, images, labels, dev, rank, world, tune_s, taylor_s,
                   "new_conv_problems_seen": w["new_conv_problems_looked_up"], "lanes": lanes,
                   "lanes_setup_s": round(lanes_s, 3)},
         "check": w["check"],
+        "dist": dist_info,
     }
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def rank_info(rank, local, dev):
+    """What proves how many ranks the collective backend saw: backend name, its world size, the sum of a one per
+    rank through the backend's all-reduce, and every rank's device (gathered through the backend)."""
+    import torch.distributed as dist
+    on_gpu = dev is not None and dev.type == "cuda"
+    me = {"rank": rank, "local_rank": local, "pid": os.getpid(), "device": str(dev) if dev is not None else "cpu",
+          "device_name": torch.cuda.get_device_name(dev) if on_gpu else "cpu",
+          "visible_gpus": torch.cuda.device_count()}
+    if on_gpu:
+        props = torch.cuda.get_device_properties(dev)
+        me["pci_bus_id"] = getattr(props, "pci_bus_id", None)
+        me["uuid"] = str(getattr(props, "uuid", ""))
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": None, "world_size": 1, "all_reduce_of_ones": 1, "ranks": [me]}
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, me)
+    one = torch.ones(1, dtype=torch.int64, device=dev if on_gpu else "cpu")
+    sdist.all_reduce_sum_(one)
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "all_reduce_of_ones": int(one.item()),
+            "ranks": everyone}
 
 
 def main():
@@ -416,7 +599,24 @@ def main():
     ap.add_argument("--no-tune", action="store_true", help="skip the MIOpen find-database warm-up of the backbone")
     ap.add_argument("--torch-forward", action="store_true",
                     help="A/B: keep the models' up-sampling, batch-norm, depthwise and 1x1 modules on their torch path")
+    ap.add_argument("--no-prefix-reuse", action="store_true",
+                    help="A/B: every candidate forwards the whole network instead of starting at the first block its group touches")
+    ap.add_argument("--rank-probe", action="store_true",
+                    help="start the ranks, report what the collective backend saw (one JSON line) and stop: no GPU work "
+                         "beyond naming the devices; with no GPU visible the ranks meet over gloo")
     args = ap.parse_args()
+    if args.rank_probe:
+        backend = "nccl" if torch.cuda.device_count() > 0 else "gloo"
+        rank, world, local = sdist.init_from_env(backend)
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        dev = torch.device("cuda", local) if torch.cuda.device_count() > 0 else None
+        info = rank_info(rank, local, dev)
+        if rank == 0:
+            print(json.dumps({"probe": "ranks", "n_gpus": args.gpus, "dist": info}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     if args.torch_forward:
         from spice_amd.nets import layers
         layers.set_library_forward(False)
@@ -439,11 +639,15 @@ def main():
 
     rank, world, local = sdist.init_from_env("nccl")
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: leave the torchrun environment unset and this file starts "
+                         "the ranks itself, or pass the same N to both")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     nat.lib()
     torch.backends.cudnn.benchmark = False
+    dist_info = rank_info(rank, local, dev)
+    if dist_info["world_size"] != args.gpus or dist_info["all_reduce_of_ones"] != args.gpus:
+        raise SystemExit(f"the collective backend saw {dist_info['world_size']} rank(s), --gpus {args.gpus}")
 
     torch.manual_seed(1234)
     t_build = time.perf_counter()
@@ -458,6 +662,8 @@ def main():
     n_cand = len(sweep.candidates)
     if args.three_launch_head:
         sweep.fused_head = False
+    if args.no_prefix_reuse:
+        sweep.prefix_reuse = False
     t_lanes = time.perf_counter()
     try:   # set-up like the construction of the sweep itself: copies of the network + their groups
         lanes = sweep.enable_lanes(args.lanes)
@@ -474,37 +680,42 @@ def main():
             sweep.forward(images)
         torch.cuda.synchronize()
         first_s = time.perf_counter() - t_first
-        strong_mode(args, sweep, images, labels, dev, rank, world, tune_s, taylor_s, build_s, first_s, lanes, lanes_s)
+        strong_mode(args, sweep, images, labels, dev, rank, world, tune_s, taylor_s, build_s, first_s, lanes, lanes_s, dist_info)
         return
     parts = sdist.partition_by_cost(sweep.candidate_costs(images), world)
     mine = parts[rank]
+    # the K timed candidates are spread evenly over the rank's share (which runs from the stem's group to the
+    # decoder's): a candidate's cost depends on where its group sits in the network, so the first K of the list
+    # would time the early groups only.  The W warm-up candidates are spread over the rest of the share.
+    n_mine = len(mine)
+    timed = ([mine[(j * n_mine) // args.steps] for j in range(args.steps)] if args.steps <= n_mine
+             else [mine[j % n_mine] for j in range(args.steps)])
+    rest = [c for c in mine if c not in set(timed)] or mine
+    warm = ([rest[(j * len(rest)) // args.warmup] for j in range(args.warmup)] if 0 < args.warmup <= len(rest)
+            else [rest[j % len(rest)] for j in range(args.warmup)])
+    todo = warm + timed
     total_steps = args.warmup + args.steps
-    todo = [mine[i % len(mine)] for i in range(total_steps)]
-    warm_list = sorted(set(todo[:args.warmup]))
-    timed_list = [i for i in dict.fromkeys(todo[args.warmup:]) if i not in set(warm_list)]
+    warm_list = sorted(set(warm))
+    timed_list = [i for i in dict.fromkeys(timed) if i not in set(warm_list)]
     sweep.prepare(warm_list)
     sweep.warm_shapes(images, warm_list)
-    with sweep.session():
-        teacher = sweep.forward(images).float().contiguous()
-        table = torch.zeros(n_cand, CLASSES, CLASSES, dtype=torch.int64, device=dev)
-        kd = torch.zeros(n_cand, 3, dtype=torch.float32, device=dev)
 
+    def timed_region(first_time):
+        """K candidates, wall-clock, barrier and device synchronisation on both sides; the first time it holds ALL
+        per-candidate work of its K candidates: launch plans and index upload, the solver lookups for their new
+        convolution shapes (up front, while nothing is queued), evaluation, the all-reduce of the tables."""
+        table.zero_()   # (outside the clock) every row is its owner's alone before the all-reduce sums the ranks' tables
+        kd.zero_()
         sweep.fork_lanes()
-        for i in range(args.warmup):
-            with sweep.lane_context(todo[i]):
-                table[todo[i]].zero_()
-            sweep.evaluate(todo[i], images, labels, teacher, table[todo[i]], kd[todo[i]])
-        sweep.join_lanes()
-        sweep.kd_events = []
         sdist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        # the timed region holds ALL per-candidate work of its K candidates: launch plans and index
-        # upload, the solver lookups for their new convolution shapes (up front, while nothing is queued), evaluation
-        sweep.prepare(timed_list)
-        if args.warm_mode == "upfront":
-            sweep.warm_shapes(images, timed_list)
-        prep_s = time.perf_counter() - t0
+        prep = 0.0
+        if first_time:
+            sweep.prepare(timed_list)
+            if args.warm_mode == "upfront":
+                sweep.warm_shapes(images, timed_list)
+            prep = time.perf_counter() - t0
         moved = 0
         for i in range(args.warmup, total_steps):
             with sweep.lane_context(todo[i]):
@@ -515,10 +726,41 @@ def main():
         sdist.all_reduce_sum_(kd)
         torch.cuda.synchronize()
         sdist.barrier()
-        elapsed = time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        sdist.all_reduce_max_(t)
+        return float(t.item()), prep, moved
+
+    with sweep.session():
+        # the un-pruned network's forward: the teacher's logits and, with prefix reuse, every block's activations
+        # (recorded either way, so that the A/B region behind the timed one can run both forms)
+        want_reuse, sweep.prefix_reuse = sweep.prefix_reuse, True
+        teacher = sweep.teacher_forward(images).float().contiguous()
+        sweep.prefix_reuse = want_reuse
+        table = torch.zeros(n_cand, CLASSES, CLASSES, dtype=torch.int64, device=dev)
+        kd = torch.zeros(n_cand, 3, dtype=torch.float32, device=dev)
+
+        sweep.fork_lanes()
+        for i in range(args.warmup):
+            with sweep.lane_context(todo[i]):
+                table[todo[i]].zero_()
+            sweep.evaluate(todo[i], images, labels, teacher, table[todo[i]], kd[todo[i]])
+        sweep.join_lanes()
+        sweep.kd_events = []
+        reused0 = sweep.units_reused
+        elapsed, prep_s, moved = timed_region(True)
+        units_reused = (sweep.units_reused - reused0) / max(args.steps, 1)
+        kd_events = sweep.kd_events
+        sweep.kd_events = None
+        # the same K candidates once more the other way (whole forward / prefix taken from the teacher pass), launch
+        # plans and solver lookups already made: the figure rounds before prefix reuse reported, kept comparable
+        table_a = table[timed].clone()
+        sweep.prefix_reuse = not sweep.prefix_reuse
+        elapsed_other, _, _ = timed_region(False)
+        sweep.prefix_reuse = not sweep.prefix_reuse
+        same_tables = bool(torch.equal(table_a, table[timed]))
+        elapsed_again, _, _ = timed_region(False)   # and the timed form again without its plans: like for like
     n_warm = len(sweep._warmed)
-    kd_events = sweep.kd_events
-    sweep.kd_events = None
     kd_events_alone = kd_events
     if lanes > 1:
         # With several candidates in flight the loss kernel shares the device with the other lane's convolutions and
@@ -531,10 +773,6 @@ def main():
                 sweep.evaluate(todo[i], images, labels, teacher, table[todo[i]], kd[todo[i]], first_lane=True)
         torch.cuda.synchronize()
         kd_events_alone, sweep.kd_events = sweep.kd_events, None
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    sdist.all_reduce_max_(t)
-    elapsed = float(t.item())
-
     kd_ms_shared = float(np.mean([a.elapsed_time(b) for a, b in kd_events])) if kd_events else float("nan")
     kd_ms = float(np.mean([a.elapsed_time(b) for a, b in kd_events_alone])) if kd_events_alone else float("nan")
     # the kernel those events bracket: the candidate's tail in one launch (up-sampling + loss + arg-max histogram over
@@ -566,9 +804,15 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": FORWARD_DTYPE_FP32 if args.fp32_forward else FORWARD_DTYPE, "data": "synthetic",
         "config": {"workload": "DeepLabV3Plus_resnet magnitude_taylor sensitivity sweep: one (channel group x "
-                               "ratio) candidate per step = gather + forward + arg-max/confusion + KD-Lite loss",
+                               "ratio) candidate per step = gather + forward + arg-max/confusion + KD-Lite loss; "
+                               + ("the forward starts at the first block the candidate's group touches, on the un-pruned "
+                                  "network's activations of the same sweep (prefix reuse); the K timed candidates are spread "
+                                  "evenly over the rank's share" if sweep.prefix_reuse else
+                                  "every candidate forwards the whole network (--no-prefix-reuse); the K timed candidates are "
+                                  "spread evenly over the rank's share"),
+                   "prefix_reuse": sweep.prefix_reuse,
                    "num_classes": CLASSES, "eval_batch": [BATCH, 3, SIZE, SIZE], "candidates": n_cand,
                    "groups": len(sweep.groups), "ratios": list(DEFAULT_RATIOS),
                    "forward": "fp32" if args.fp32_forward else (
@@ -603,9 +847,23 @@ def main():
                   "lanes": lanes, "lanes_setup_s": round(lanes_s, 3),
                   "quota_layers": len(quotas), "gather_MB_per_candidate": round(moved / max(args.steps, 1) / 1e6, 2)},
     }
+    # the same K candidates the other way, and the timed form again, both with launch plans and lookups already made
+    k_other = round(world * args.steps / elapsed_other, 3)
+    k_again = round(world * args.steps / elapsed_again, 3)
+    result["value_full_forward" if sweep.prefix_reuse else "value_prefix_reuse"] = k_other
+    result["value_without_plans" ] = k_again
+    result["prefix_reuse"] = {
+        "on_in_timed_region": sweep.prefix_reuse, "units_reused_per_candidate": round(units_reused, 2),
+        "units": len(sweep._tape) if sweep._tape is not None else 0,
+        "activations_MB": round(sweep._tape.nbytes() / 1e6, 1) if sweep._tape is not None else 0.0,
+        "same_K_candidates_again": {"prefix_reuse": k_again if sweep.prefix_reuse else k_other,
+                                    "full_forward": k_other if sweep.prefix_reuse else k_again,
+                                    "note": "launch plans and solver lookups already made in the timed region; value holds them"},
+        "confusion_matrices_identical_both_ways": same_tables}
+    result["dist"] = dist_info
     if rank == 0 and not args.torch_forward and not args.fp32_forward:
         # candidates of the first lane: one after the other on the current stream
-        probe = [c for c in dict.fromkeys(todo[args.warmup:]) if sweep.lane_index(c) == 0][:8]
+        probe = [c for c in dict.fromkeys(todo[args.warmup:]) if sweep.lane_index(c) == 0][::4][:8]
         result["forward_roofline"] = forward_probe(sweep, probe, images, labels, teacher, table, kd)
     if not args.no_strong_block:
         # The strong-scaling figure beside the weak one: the whole sweep, all candidates shared by the ranks, on a
@@ -615,6 +873,7 @@ def main():
         fresh = SensitivitySweep(model, CLASSES, DEFAULT_RATIOS, ignored_layers=ignored,
                                  autocast_dtype=None if args.fp32_forward else torch.float16)
         fresh.enable_lanes(lanes)
+        fresh.prefix_reuse = sweep.prefix_reuse
         w = whole_sweep(fresh, images, labels, dev, rank, world)
         w["scaling"] = "strong"
         w["workload"] = STRONG_WORKLOAD
@@ -624,7 +883,7 @@ def main():
         if not args.no_kernel_table:
             result["kernels"] = kernel_table(dev)
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_candidate_baseline(model, sweep, images, labels)
+            result["cpu_baseline"] = cpu_candidate_baseline(model, sweep, images, labels, ignored)
             result["cpu_baseline"]["gpu_over_cpu"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
     if rank == 0:
         print(json.dumps(result), flush=True)

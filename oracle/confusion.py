@@ -25,6 +25,20 @@ def update_confusion(conf: np.ndarray, preds: np.ndarray, target: np.ndarray, nu
     conf += hist.reshape(num_classes, num_classes)  # raises if a prediction overflowed the table
 
 
+def update_confusion_torch(conf: torch.Tensor, preds: torch.Tensor, target: torch.Tensor, num_classes: int) -> None:
+    """The same function as the torch op sequence the reference runs (baseline/eval/metrics.py:12-19: two
+    flattening views, the range mask, two compacting gathers, multiply-add, bincount, in-place add), on CPU
+    tensors: what the CPU leg of the benchmark times beside the HIP kernel."""
+    p = preds.reshape(-1)
+    t = target.reshape(-1)
+    valid = (t >= 0) & (t < num_classes)
+    p = p[valid]
+    t = t[valid]
+    idx = t * num_classes + p
+    binc = torch.bincount(idx, minlength=num_classes * num_classes)
+    conf += binc.view(num_classes, num_classes)
+
+
 def argmax_first(logits: np.ndarray) -> np.ndarray:
     """logits.argmax(dim=1) as used at baseline/eval/inference.py:47 (first maximum wins)."""
     return np.argmax(logits, axis=1).astype(np.int64)

@@ -128,7 +128,10 @@ class ASPP(nn.Module):
                 at += c
         else:
             y = torch.cat([b(x) for b in self.convs], dim=1)
-        return self.project[2](conv1x1_bn(self.project[0], self.project[1], y))
+        pr = self.project
+        if type(pr) is not nn.Sequential or len(pr) != 3 or layers._hooked(pr):
+            return pr(y)   # a replaced or listened-to container: called as the module it is
+        return pr[2](conv1x1_bn(pr[0], pr[1], y))
 
 
 class DeepLabV3PlusDecoder(nn.Module):
@@ -148,10 +151,38 @@ class DeepLabV3PlusDecoder(nn.Module):
             out_channels)
         self.out_channels = out_channels
 
+    #: a pass of a prefix.PrefixTape, attached by the caller for the duration of one forward (None: the plain forward)
+    _tape = None
+
+    def prefix_units(self, prefix: str = "decoder"):
+        """The first units of this decoder in execution order (prefix.PrefixTape): the ASPP block, then the separable
+        convolution + batch-norm behind it.  What follows (up-sampling, high-resolution branch, fusion block) writes
+        into a buffer of its own per forward and always runs."""
+        units = [(f"{prefix}.aspp.0", (f"{prefix}.aspp.0",)),
+                 (f"{prefix}.aspp.tail", (f"{prefix}.aspp.1", f"{prefix}.aspp.2"))]
+        self._unit_names = [n for n, _ in units]
+        return units
+
+    def _plain_aspp(self) -> bool:
+        a = self.aspp
+        return (type(a) is nn.Sequential and len(a) == 3 and type(a[1]) is SeparableConv2d and type(a[1][1]) is Conv1x1
+                and not (layers._hooked(a) or layers._hooked(a[1])))
+
+    def _aspp_tail(self, y):
+        a = self.aspp   # separable 3x3 (depthwise, pointwise) -> batch-norm + ReLU: the pointwise pair in one call
+        if self._plain_aspp():
+            return conv1x1_bn(a[1][1], a[2], a[1][0](y))
+        return a[2](a[1](y))
+
     def forward(self, features: List[torch.Tensor]):
         a = self.aspp   # ASPP -> separable 3x3 (depthwise, pointwise) -> batch-norm + ReLU
-        deep = (conv1x1_bn(a[1][1], a[2], a[1][0](a[0](features[-1]))) if type(a[1][1]) is Conv1x1
-                else a(features[-1]))
+        tape = self._tape
+        if tape is not None:
+            deep = tape.run(self._unit_names[1], self._aspp_tail, tape.run(self._unit_names[0], a[0], features[-1]))
+        elif self._plain_aspp():
+            deep = self._aspp_tail(a[0](features[-1]))
+        else:
+            deep = a(features[-1])   # a replaced or listened-to container: called as the module it is
         skip = features[2]
         s = int(self.up.scale_factor)
         if (_writes_in_place(skip) and self.up.scale_factor == s and deep.dim() == 4
@@ -190,12 +221,23 @@ class UnetDecoder(nn.Module):
                                     for i, s, o in zip(in_chs, skip_chs, decoder_channels))
         self.out_channels = decoder_channels[-1]
 
+    #: a pass of a prefix.PrefixTape, attached by the caller for the duration of one forward (None: the plain forward)
+    _tape = None
+
+    def prefix_units(self, prefix: str = "decoder"):
+        """The units of this decoder in execution order: its blocks (prefix.PrefixTape)."""
+        units = [(f"{prefix}.blocks.{i}", (f"{prefix}.blocks.{i}",)) for i in range(len(self.blocks))]
+        self._unit_names = [n for n, _ in units]
+        return units
+
     def forward(self, features: List[torch.Tensor]):
         feats = features[1:][::-1]
         x = feats[0]
         skips = feats[1:]
+        tape = self._tape
         for i, block in enumerate(self.blocks):
-            x = block(x, skips[i] if i < len(skips) else None)
+            skip = skips[i] if i < len(skips) else None
+            x = block(x, skip) if tape is None else tape.run(self._unit_names[i], block, x, skip)
         return x
 
 
@@ -266,6 +308,24 @@ class SegmentationModel(nn.Module):
 
     def forward(self, x):
         return self.segmentation_head(self.decoder(self.encoder(x)))
+
+    def prefix_units(self):
+        """(unit name, prefixes of the names of its modules) in execution order, for prefix.PrefixTape: the encoder's
+        units followed by the decoder's first ones.  Empty when the network's parts do not name any, or when the
+        forward is not this class's (a subclass may run its parts in another order)."""
+        if type(self).forward is not SegmentationModel.forward or not hasattr(self.encoder, "prefix_units"):
+            return []
+        units = list(self.encoder.prefix_units("encoder"))
+        if hasattr(self.decoder, "prefix_units"):
+            units += list(self.decoder.prefix_units("decoder"))
+        return units
+
+    def attach_tape(self, tape_pass) -> None:
+        """Route the next forwards through `tape_pass` (a pass of a prefix.PrefixTape built from prefix_units());
+        None detaches."""
+        self.encoder._tape = tape_pass
+        if hasattr(self.decoder, "prefix_units"):
+            self.decoder._tape = tape_pass
 
     def forward_to_head(self, x):
         """The forward up to the head's convolution, for the kernels that up-sample on the fly (the tail of a sweep

@@ -109,7 +109,34 @@ class EfficientNetB3Encoder(nn.Module):
             stages.append(nn.Sequential(*blocks))
         self.blocks = nn.Sequential(*stages)
 
+    #: a pass of a prefix.PrefixTape, attached by the caller for the duration of one forward (None: the plain forward)
+    _tape = None
+
+    def prefix_units(self, prefix: str = "encoder"):
+        """The units of this encoder in execution order: the stem, then every block (prefix.PrefixTape)."""
+        units = [(f"{prefix}.stem", (f"{prefix}.conv_stem", f"{prefix}.bn1", f"{prefix}.act1"))]
+        for i, stage in enumerate(self.blocks):
+            units += [(f"{prefix}.blocks.{i}.{j}", (f"{prefix}.blocks.{i}.{j}",)) for j in range(len(stage))]
+        self._unit_names = [n for n, _ in units]
+        return units
+
+    def _stem(self, x):
+        return self.act1(self.bn1(self.conv_stem(x)))
+
+    def _forward_taped(self, x, tape) -> List[torch.Tensor]:
+        names = iter(self._unit_names)
+        h = tape.run(next(names), self._stem, x)
+        feats = [x, h]
+        for i, stage in enumerate(self.blocks):
+            for block in stage:
+                h = tape.run(next(names), block, h)
+            if i in (1, 2, 4, 6):   # the stages whose outputs are the feature maps
+                feats.append(h)
+        return feats
+
     def forward(self, x) -> List[torch.Tensor]:
+        if self._tape is not None:
+            return self._forward_taped(x, self._tape)
         f0 = x
         f1 = self.act1(self.bn1(self.conv_stem(x)))
         y = self.blocks[1](self.blocks[0](f1))

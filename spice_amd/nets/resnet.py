@@ -33,6 +33,12 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         m = self._modules   # the sub-modules from their table: nn.Module's attribute fallback is several probes per name
         conv2, bn2, conv3, bn3, downsample = m["conv2"], m["bn2"], m["conv3"], m["bn3"], m.get("downsample")
+        if downsample is not None and (type(downsample) is not nn.Sequential or len(downsample) != 2
+                                       or layers._hooked(downsample)):
+            # a shortcut that is not the plain (convolution, batch-norm) pair, or one somebody listens to: called as
+            # the module it is (its hooks fire, a replacement's forward runs)
+            h2 = self.bn2(self.conv2(self.bn1(self.conv1(x))))
+            return self.bn3(self.conv3(h2), downsample(x))
         h1 = conv1x1_bn(m["conv1"], m["bn1"], x)
         out = conv3x3_bn(conv2, bn2, h1)   # one launch of the library's kernel at inference, else None
         if out is not None:
@@ -82,6 +88,17 @@ class ResNet50Encoder(nn.Module):
 
     #: set by a model whose decoder never reads the first feature map (DeepLabV3+): the stem then does not store it
     skip_stem_feature = False
+    #: a pass of a prefix.PrefixTape, attached by the caller for the duration of one forward (None: the plain forward)
+    _tape = None
+    _STAGES = ("layer1", "layer2", "layer3", "layer4")
+
+    def prefix_units(self, prefix: str = "encoder"):
+        """The units of this encoder in execution order: the stem, then every bottleneck (prefix.PrefixTape)."""
+        units = [(f"{prefix}.stem", (f"{prefix}.conv1", f"{prefix}.bn1", f"{prefix}.maxpool"))]
+        for stage in self._STAGES:
+            units += [(f"{prefix}.{stage}.{j}", (f"{prefix}.{stage}.{j}",)) for j in range(len(self._modules[stage]))]
+        self._unit_names = [n for n, _ in units]
+        return units
 
     def _stem(self, x):
         """(bn1(conv1(x)), its max-pooling).  On the inference path of a HIP device the batch-norm, the ReLU and the
@@ -99,7 +116,19 @@ class ResNet50Encoder(nn.Module):
         f1 = self.bn1(y)
         return f1, mp(f1)
 
+    def _forward_taped(self, x, tape) -> List[torch.Tensor]:
+        names = iter(self._unit_names)
+        f1, h = tape.run(next(names), self._stem, x)
+        feats = [x, f1]
+        for stage in self._STAGES:
+            for block in self._modules[stage]._modules.values():
+                h = tape.run(next(names), block, h)
+            feats.append(h)
+        return feats
+
     def forward(self, x) -> List[torch.Tensor]:
+        if self._tape is not None:
+            return self._forward_taped(x, self._tape)
         f0 = x
         f1, pooled = self._stem(x)
         f2 = self.layer1(pooled)

@@ -7,7 +7,9 @@ against the un-pruned model's logits.  Composed from the reference's primitives;
 itself only runs the one-shot Taylor analysis (pruning/pruning_core.py:99-133).
 
 Per candidate the device sees: one gather launch (slice the group's tensors), the forward of the
-sliced network up to the head's convolution (the library's kernels under fp16 autocast) and ONE
+sliced network from the first block the group touches up to the head's convolution (the library's
+kernels under fp16 autocast; what the blocks in front of it produce is what they produced in the
+un-pruned network's forward of the same sweep, bit for bit, and is taken from there) and ONE
 launch for the rest: the head's bilinear up-sampling, the KD-Lite loss against the un-pruned
 network's logits (whose softmax is taken once per sweep) and the arg-max + confusion histogram,
 without the full-size logits ever being written.  Networks whose head does not fit that launch run
@@ -37,6 +39,7 @@ from . import ops
 from .engine import MagnitudeImportance, MagnitudePruner
 from .engine.pruner import SliceJob
 from .nets.layers import Conv1x1, StemConv7x7, conv3x3_served_by_library
+from .nets.prefix import PrefixTape
 
 DEFAULT_RATIOS = (0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9)
 
@@ -95,7 +98,15 @@ class SensitivitySweep:
         #: (SPICE_SWEEP_PREPARED_TEACHER=0: the head kernel reads the teacher's logits)
         self.prepared_teacher = os.environ.get("SPICE_SWEEP_PREPARED_TEACHER", "1") != "0"
         self._teacher_src, self._teacher_key, self._teacher_prepared = None, None, None
-        self._geometry, self._geometry_for, self._warmed, self._fresh_logits = {}, None, set(), None
+        self._geometry, self._geometry_for, self._warmed = {}, None, set()
+        #: a candidate's forward starts at the first block its group touches, on the activations the un-pruned
+        #: network produced in front of it (recorded by teacher_forward); SPICE_SWEEP_PREFIX_REUSE=0: every candidate
+        #: forwards the whole network
+        self.prefix_reuse = os.environ.get("SPICE_SWEEP_PREFIX_REUSE", "1") != "0"
+        self._tape: Optional[PrefixTape] = None
+        self._tape_src, self._tape_key = None, None
+        self._first_unit: Dict[int, int] = {}
+        self.units_reused = 0   # units whose recorded activations stood in for a launch, over all candidates so far
 
     # -- cost of a candidate, for balancing ranks ---------------------------------------------
     #: share of a candidate's time that does not shrink with the network (host work per launch,
@@ -149,23 +160,82 @@ class SensitivitySweep:
             wo = (w + 2 * mod.padding[1] - mod.dilation[1] * (mod.kernel_size[1] - 1) - 1) // mod.stride[1] + 1
             macs[mod] = float(n * ho * wo)   # output positions; times weight elements below
         total = sum(p * mod.weight.numel() for mod, p in macs.items())
+        # with the prefix taken from the un-pruned network's forward, the units in front of the group's first one
+        # cost nothing: their convolutions' multiply-accumulates, by unit
+        tape = self._ensure_tape() if self.prefix_reuse else None
+        before = None
+        if tape is not None:
+            names = {m: n for n, m in self.model.named_modules()}
+            per_unit = [0.0] * (len(tape) + 1)
+            for mod, p in macs.items():
+                per_unit[tape.unit_of(names[mod])] += p * mod.weight.numel()
+            before = np.concatenate([[0.0], np.cumsum(per_unit)])   # before[k] = work of the units in front of k
         out = []
+        fixed = self.FIXED_COST_SHARE if tape is None else self.FIXED_COST_SHARE_PREFIX
         for cand in self.candidates:
             g = self.groups[cand.group]
-            gone = 0.0
+            gone = 0.0 if before is None else float(before[self.first_unit(cand.index)])
             for mod, (cin, cout, groups) in self._sliced_conv_dims(g, len(cand.pruned)).items():
                 if mod in macs:
                     k = mod.kernel_size[0] * mod.kernel_size[1]
                     gone += macs[mod] * (mod.weight.numel() - cout * (cin // max(groups, 1)) * k)
-            cand.cost = self.FIXED_COST_SHARE + (1.0 - self.FIXED_COST_SHARE) * (1.0 - gone / max(total, 1.0))
+            cand.cost = fixed + (1.0 - fixed) * (1.0 - gone / max(total, 1.0))
             out.append(cand.cost)
         return out
 
+    # -- the un-pruned network's activations in front of a candidate's first block ---------------------------
+    #: FIXED_COST_SHARE when candidates start at their group's first block (the fixed part no longer holds the
+    #: unchanged layers' memory-bound kernels in front of it): tools/partition_balance.py
+    FIXED_COST_SHARE_PREFIX = 0.45
+
+    def _ensure_tape(self) -> Optional[PrefixTape]:
+        """The tape of the primary network's units (None: the network names no units)."""
+        if self._tape is None:
+            units = (self.model.prefix_units() if hasattr(self.model, "prefix_units") and hasattr(self.model, "attach_tape")
+                     else [])
+            self._tape = PrefixTape(units) if units else None
+        return self._tape
+
+    def first_unit(self, index: int) -> int:
+        """Index of the first unit (execution order) that runs a module of candidate `index`'s group: the units in
+        front of it see the same inputs and weights as in the un-pruned network."""
+        k = self._first_unit.get(index)
+        if k is None:
+            tape = self._ensure_tape()
+            g = self.groups[self.candidates[index].group]
+            k = 0 if tape is None else tape.first_touched(m.name for m in g.members)
+            self._first_unit[index] = k
+        return k
+
+    def teacher_forward(self, images: torch.Tensor) -> torch.Tensor:
+        """The un-pruned network's logits on `images`; with prefix reuse on, the pass also records every unit's
+        output, for the candidates evaluated on the same batch tensor afterwards."""
+        tape = self._ensure_tape() if self.prefix_reuse else None
+        if tape is None or not images.is_cuda:
+            return self.forward(images)
+        self.join_lanes()   # candidates still in flight on the lanes' streams read the activations dropped here
+        self.model.attach_tape(tape.recorder())
+        try:
+            logits = self.forward(images)
+        finally:
+            self.model.attach_tape(None)
+        # the tensor object is part of the key and is kept alive with the activations (an address alone can come
+        # back from the allocator holding another batch)
+        self._tape_src, self._tape_key = images, (images._version, tuple(images.shape))
+        if not tape.complete():
+            self._tape_src = None
+        return logits
+
+    def _tape_for(self, images: torch.Tensor) -> Optional[PrefixTape]:
+        if (self.prefix_reuse and self._tape is not None and self._tape_src is images
+                and self._tape_key == (images._version, tuple(images.shape))):
+            return self._tape
+        return None
+
     def _ensure_geometry(self, images: torch.Tensor) -> None:
         """Input shape and dtype of every convolution for this batch geometry (one hooked forward of the
-        un-pruned network, whose logits are kept for run() to use as the teacher's)."""
+        un-pruned network; hooked modules run one by one on torch's kernels, so nothing else is kept from it)."""
         shape = tuple(images.shape)
-        self._fresh_logits = None
         if self._geometry_for == shape:
             return
         self._geometry = {}
@@ -174,7 +244,7 @@ class SensitivitySweep:
             for m in self.model.modules() if isinstance(m, nn.Conv2d)]
         try:
             with self.session():
-                self._fresh_logits = self.forward(images)
+                self.forward(images)
         finally:
             for h in hooks:
                 h.remove()
@@ -365,14 +435,20 @@ class SensitivitySweep:
         algorithmic bytes of the gather launch.  first_lane: on this network and the current stream whatever lane
         the candidate belongs to (measurements that want one candidate on the device at a time)."""
         lane = self if first_lane else self._lane_of(index)
+        tape = self._tape_for(images)
+        replay = tape.replay(self.first_unit(index)) if tape is not None else None
         prepared = None
         if self.fused_head and self.prepared_teacher and teacher_logits is not None and kd_out is not None:
             prepared = self._teacher_parts(teacher_logits)
         if lane is not self:
             lane.fused_head = self.fused_head
             with torch.cuda.stream(lane._stream):
-                return lane._evaluate(index, images, labels, teacher_logits, conf_out, kd_out, self.kd_events, prepared)
-        return self._evaluate(index, images, labels, teacher_logits, conf_out, kd_out, self.kd_events, prepared)
+                moved = lane._evaluate(index, images, labels, teacher_logits, conf_out, kd_out, self.kd_events, prepared, replay)
+        else:
+            moved = self._evaluate(index, images, labels, teacher_logits, conf_out, kd_out, self.kd_events, prepared, replay)
+        if replay is not None:
+            self.units_reused += replay.reused
+        return moved
 
     def _teacher_parts(self, teacher_logits: torch.Tensor):
         """(probabilities at the distillation temperature, per-pixel sum p ln p) of the teacher's logits, taken once
@@ -390,11 +466,14 @@ class SensitivitySweep:
 
     def _evaluate(self, index: int, images: torch.Tensor, labels: torch.Tensor, teacher_logits: Optional[torch.Tensor],
                   conf_out: torch.Tensor, kd_out: Optional[torch.Tensor], kd_events: Optional[list],
-                  prepared=None) -> int:
+                  prepared=None, replay=None) -> int:
         if index not in self.jobs:
             self._prepare([index])
         job = self.jobs[index]
         moved = job.run(keep_undo=True)
+        if replay is not None:
+            # the units in front of the group's first one return what the un-pruned network produced there
+            self.model.attach_tape(replay)
         try:
             with_kd = teacher_logits is not None and kd_out is not None
             e0 = e1 = None
@@ -440,6 +519,8 @@ class SensitivitySweep:
                         kd_events.append((e0, e1))
                     kd_out.copy_(out3)
         finally:
+            if replay is not None:
+                self.model.attach_tape(None)
             job.undo()
         return moved
 
@@ -468,7 +549,6 @@ class SensitivitySweep:
         ph: Dict[str, float] = {}
         t = time.perf_counter()
         all_costs = self.candidate_costs(images)
-        unpruned_logits, self._fresh_logits = self._fresh_logits, None   # this call's geometry pass, if it ran one
         costs = [all_costs[i] for i in indices]
         parts = sdist.partition_by_cost(costs, world)
         mine = [indices[k] for k in parts[rank]]
@@ -487,8 +567,11 @@ class SensitivitySweep:
         t0 = time.perf_counter()
         with self.session():
             teacher = None
-            if with_kd:   # the un-pruned network's logits: the geometry pass of this call already computed them
-                teacher = (unpruned_logits if unpruned_logits is not None else self.forward(images)).float().contiguous()
+            # the un-pruned network's forward: the teacher's logits, and the activations the candidates start from
+            unpruned = self.teacher_forward(images)
+            if with_kd:
+                teacher = unpruned.float().contiguous()
+            del unpruned
             dev_sync()
             ph["teacher_forward_s"], t = time.perf_counter() - t, time.perf_counter()
             self.fork_lanes()

@@ -551,3 +551,63 @@ def test_baseline_run_eval_prints_the_table(dev, tmp_path, capsys):
     for r in results:
         assert f"{r['model']:<30} {r['miou']:<10.4f} {r['mean_acc']:<10.4f}" in out
         assert 0.0 <= r["miou"] <= 1.0 and len(r["per_class_iou"]) == 5
+
+
+def test_sweep_prefix_reuse_gives_the_tables_of_the_whole_forward(dev):
+    """Every candidate of the DeepLabV3Plus_resnet 21-class sweep on the benchmark's 8x3x512x512 batch, forwarded from
+    the first block its group touches (the activations in front of it taken from the un-pruned network's forward of
+    the same run) and forwarded whole: all 414 confusion matrices identical, losses to 1e-5 (the loss kernel sums
+    its workgroups' partial sums in the order they finish).  The blocks in front of a group's first module see the
+    same inputs and weights as in the un-pruned network and run the same deterministic kernels."""
+    from spice_amd.sweep import DEFAULT_RATIOS
+    torch.manual_seed(1234)
+    model = nets.create_model("DeepLabV3Plus", "resnet50", 21).to(dev).eval()
+    ignored = [m for m in model.segmentation_head.modules() if isinstance(m, nn.Conv2d)]
+    x = torch.from_numpy(synth.normal(1234, 50, 8 * 3 * 512 * 512).reshape(8, 3, 512, 512)).to(dev)
+    lab = torch.from_numpy(synth.label_map(1234, 8, 512, 512, 21, "blocky", ignore_share=0.05)).to(dev)
+    results, reused = [], []
+    for reuse in (True, False):
+        sweep = SensitivitySweep(model, 21, DEFAULT_RATIOS, ignored_layers=ignored)
+        sweep.prefix_reuse = reuse
+        assert sweep.enable_lanes(2) == 2
+        results.append(sweep.run(x, lab))
+        reused.append(sweep.units_reused)
+        assert len(sweep.candidates) == 414
+    assert reused[1] == 0 and reused[0] > 414 * 5          # 19 units; the average candidate starts past the middle
+    assert torch.equal(results[0]["confusion"], results[1]["confusion"])
+    assert torch.allclose(results[0]["kd"], results[1]["kd"], rtol=1e-5, atol=1e-7)
+    assert int(results[0]["confusion"].sum()) == 414 * int((lab != 255).sum())
+    # first units: the stem's group starts at unit 0, a decoder group behind every encoder unit
+    first = [sweep.first_unit(c.index) for c in sweep.candidates]
+    assert first[0] == 0 and max(first) >= 17
+
+
+@pytest.mark.parametrize("arch,enc", [("Unet", "timm-efficientnet-b3"), ("FPN", "resnet50"), ("Unet", "resnet50")])
+def test_sweep_prefix_reuse_on_the_other_networks(dev, arch, enc):
+    """The encoders' and the U-Net decoder's units on networks whose forward goes through MIOpen (which may pick
+    another algorithm on a later call): candidates with and without prefix reuse agree up to a pixel or two on an
+    arg-max tie, and a replayed forward returns the recorded activations themselves."""
+    torch.manual_seed(5)
+    model = nets.create_model(arch, enc, 7).to(dev).eval()
+    ignored = [m for m in model.segmentation_head.modules() if isinstance(m, nn.Conv2d)]
+    x = torch.randn(2, 3, 64, 64, device=dev)
+    lab = torch.from_numpy(synth.label_map(4, 2, 64, 64, 7, "blocky")).to(dev)
+    out = []
+    for reuse in (True, False):
+        sweep = SensitivitySweep(model, 7, ratios=(0.5,), ignored_layers=ignored, autocast_dtype=None)
+        sweep.prefix_reuse = reuse
+        pick = list(range(0, len(sweep.candidates), 3))
+        out.append(sweep.run(x, lab, indices=pick))
+        assert (sweep.units_reused > 0) == reuse
+    diff = (out[0]["confusion"] - out[1]["confusion"]).abs().sum(dim=(1, 2))
+    assert int(diff.max()) <= 4
+    assert torch.allclose(out[0]["kd"], out[1]["kd"], rtol=1e-3, atol=1e-5)
+    from spice_amd.nets.prefix import PrefixTape
+    tape = PrefixTape(model.prefix_units())
+    with torch.no_grad():
+        model.attach_tape(tape.recorder())
+        y0 = model(x)
+        model.attach_tape(tape.replay(len(tape)))
+        y1 = model(x)
+        model.attach_tape(None)
+    assert tape.complete() and torch.allclose(y0, y1, rtol=1e-4, atol=1e-5)

@@ -97,6 +97,73 @@ def test_confusion_config5_size_properties(dev):
     assert int(conf.sum()) == int((lab != 255).sum())
 
 
+def _config5_logits(dev, dtype, n, c, h, w):
+    """Device logits in steps of 1/2 (many exact ties: the first maximum must win), and the oracle's first-maximum
+    arg-max of the same values, image by image on the host."""
+    g = torch.Generator(device=dev).manual_seed(5)
+    logits = torch.empty(n, c, h, w, device=dev, dtype=dtype)
+    for i in range(n):   # image by image: no second full-size temporary
+        logits[i] = (torch.randn(c, h, w, device=dev, generator=g) * 3).mul_(2).round_().div_(2).to(dtype)
+    pred = np.empty((n, h, w), dtype=np.int64)
+    for i in range(n):
+        pred[i] = oc.argmax_first(logits[i].float().cpu().numpy()[None])[0]
+    return logits, pred
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_argmax_confusion_config5_size(dev, dtype):
+    """The evaluation loops' fused entry point at the size of the 1024x2048, 19-class, batch-32 evaluation
+    (baseline/train_test_quant.py:205-229): [32,19,1024,2048] logits - 2.5 GB as fp16, past 2^31 bytes, 5.1 GB as
+    fp32 - bit-exact against the oracle's arg-max + histogram and against confusion_update on torch's arg-max."""
+    c, n, h, w = 19, 32, 1024, 2048
+    lab = synth.label_map(12, n, h, w, c, "uniform", ignore_share=0.10)
+    logits, pred = _config5_logits(dev, dtype, n, c, h, w)
+    assert logits.numel() * logits.element_size() > 2 ** 31
+    ref = np.zeros((c, c), dtype=np.int64)
+    oc.update_confusion(ref, pred, lab, c)
+    lab_d = torch.from_numpy(lab).to(dev)
+    conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
+    ops.argmax_confusion_update(conf, logits, lab_d, c)
+    np.testing.assert_array_equal(conf.cpu().numpy(), ref)
+    two_step = torch.zeros(c, c, dtype=torch.int64, device=dev)
+    ops.confusion_update(two_step, logits.argmax(1), lab_d, c)
+    np.testing.assert_array_equal(two_step.cpu().numpy(), ref)
+    assert int(conf.sum()) == int((lab != 255).sum())
+    # the last image alone (its logits start past 2^31 bytes): a wrapped offset would read another image
+    last = torch.zeros(c, c, dtype=torch.int64, device=dev)
+    ops.argmax_confusion_update(last, logits[n - 1:], lab_d[n - 1:], c)
+    ref_last = np.zeros((c, c), dtype=np.int64)
+    oc.update_confusion(ref_last, pred[n - 1:], lab[n - 1:], c)
+    np.testing.assert_array_equal(last.cpu().numpy(), ref_last)
+
+
+def test_upsample_argmax_confusion_config5_size(dev):
+    """[32,19,256,512] fp16 head logits -> 1024x2048 inside the histogram launch: bit-exact against the two
+    launches it replaces (up-sampling kernel, then arg-max histogram), against confusion_update on torch's
+    arg-max of the up-sampled logits and against the oracle's histogram of that arg-max."""
+    c, n, h, w = 19, 32, 1024, 2048
+    lab = synth.label_map(13, n, h, w, c, "blocky", ignore_share=0.10)
+    lab_d = torch.from_numpy(lab).to(dev)
+    g = torch.Generator(device=dev).manual_seed(6)
+    low = (torch.randn(n, c, h // 4, w // 4, device=dev, generator=g) * 3).half()
+    conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
+    assert ops.upsample_argmax_confusion(conf, low, lab_d, align_corners=True, scale_factor=4.0), \
+        "the one-launch form must cover the 1024x2048 evaluation"
+    full = ops.upsample_bilinear(low, scale_factor=4.0, align_corners=True, out_dtype=torch.float32)
+    assert full.numel() * 4 > 2 ** 31
+    two = torch.zeros(c, c, dtype=torch.int64, device=dev)
+    ops.argmax_confusion_update(two, full, lab_d, c)
+    assert torch.equal(conf, two)
+    pred = full.argmax(1)
+    three = torch.zeros(c, c, dtype=torch.int64, device=dev)
+    ops.confusion_update(three, pred, lab_d, c)
+    assert torch.equal(conf, three)
+    ref = np.zeros((c, c), dtype=np.int64)
+    oc.update_confusion(ref, pred.cpu().numpy(), lab, c)
+    np.testing.assert_array_equal(conf.cpu().numpy(), ref)
+    assert int(conf.sum()) == int((lab != 255).sum())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 21, 64, 64), (1, 5, 15, 17), (1, 19, 3, 8)])
 def test_argmax_confusion_vs_oracle(dev, dtype, shape):

@@ -85,6 +85,17 @@ def test_confusion_oracle_matches_reference(name):
     assert m["miou"] == CF[f"{name}/pc_means"][0] and m["mean_acc"] == CF[f"{name}/pc_means"][1]
 
 
+@pytest.mark.parametrize("name", [str(x) for x in CF["names"]])
+def test_confusion_torch_op_sequence_matches_reference(name):
+    """The torch-op form the benchmark's CPU leg times: same matrices as the reference's function.  Cases whose
+    predictions fall outside the table make the reference's bincount view raise; so must this."""
+    c = int(CF[f"{name}/num_classes"][0])
+    conf = torch.zeros(c, c, dtype=torch.int64)
+    for k in range(2):
+        oc.update_confusion_torch(conf, torch.from_numpy(CF[f"{name}/pred{k}"]), torch.from_numpy(CF[f"{name}/target{k}"]), c)
+        np.testing.assert_array_equal(conf.numpy(), CF[f"{name}/conf{k}"])
+
+
 def test_confusion_sum_is_valid_pixel_count():
     name = "c21_uniform"
     c = 21

@@ -323,6 +323,8 @@ class SegmentationModel(nn.Module):
     def attach_tape(self, tape_pass) -> None:
         """Route the next forwards through `tape_pass` (a pass of a prefix.PrefixTape built from prefix_units());
         None detaches."""
+        if tape_pass is not None and not hasattr(self.encoder, "_unit_names"):
+            self.prefix_units()   # a copy of the network that was never asked: its parts learn their unit names
         self.encoder._tape = tape_pass
         if hasattr(self.decoder, "prefix_units"):
             self.decoder._tape = tape_pass

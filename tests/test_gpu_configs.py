@@ -243,19 +243,21 @@ def test_sweep_candidates_at_the_benchmark_size_against_the_cpu_path(dev):
         assert int(got16.sum()) == n_valid
         moved_b = int(np.abs(got16 - got32).sum()) // 2
         miou16 = float(miou_from_confusion(res16["confusion"][i]).item())
+        # total and CE relative; the KL term of two nearly equal networks is a difference of nearly equal numbers
+        # (1e-6 and below here): absolute
         report.append((root, moved_a1, moved_a2, abs(miou32 - miou_cpu), moved_b, abs(miou16 - miou32),
-                       [abs(res32["kd"][i, k].item() - float(ref_cpu[key])) / max(abs(float(ref_cpu[key])), 1e-12)
+                       [abs(res32["kd"][i, k].item() - float(ref_cpu[key])) / (max(abs(float(ref_cpu[key])), 1e-12) if k < 2 else 1.0)
                         for k, key in enumerate(("total", "ce", "kd"))],
-                       [abs(res16["kd"][i, k].item() - res32["kd"][i, k].item()) / max(abs(res32["kd"][i, k].item()), 1e-12)
-                        for k in range(3)]))
-    print("\n[bench-size parity] root, px moved (a1, a2), |dmIoU| a2, px moved fp16, |dmIoU| fp16, loss rel (a2), loss rel fp16")
+                       [abs(res16["kd"][i, k].item() - res32["kd"][i, k].item()) / (max(abs(res32["kd"][i, k].item()), 1e-12) if k < 2 else 1.0)
+                        for k in range(3)], float(ref_cpu["kd"])))
+    print("\n[bench-size parity] root, px moved (a1, a2), |dmIoU| a2, px moved fp16, |dmIoU| fp16, "
+          "loss deltas (a2) [rel total, rel ce, abs kd], the same for fp16 against fp32, kd of the CPU path")
     for row in report:
         print("   ", row)
-    for root, a1, a2, dm2, b, dmb, l2, lb in report:
-        # fp32 forward on two machines' kernels: a few dozen of the 2.1 M pixels sit on an arg-max tie
-        assert a2 <= 2100 * 0.1 and dm2 <= 1e-4, (root, a2, dm2)      # <= 1e-4 of the pixels
-        assert l2[0] <= 1e-4 and l2[1] <= 1e-4, (root, l2)             # total and CE; the KL of two near-equal networks is
-        # a difference of nearly equal numbers: bounded absolutely through `total`
-        # fp16 forward: the logits carry 1e-3 relative rounding; bounded share of pixels, bounded mIoU shift
-        assert b <= 0.02 * n_valid and dmb <= 5e-3, (root, b, dmb)
-        assert lb[0] <= 2e-2, (root, lb)
+    for root, a1, a2, dm2, b, dmb, l2, lb, _ in report:
+        # fp32 forward on the two machines' kernels (measured: 1-3 of the 2.1 M pixels sit on an arg-max tie)
+        assert a2 <= 16 and dm2 <= 1e-6, (root, a2, dm2)
+        assert l2[0] <= 1e-5 and l2[1] <= 1e-5 and l2[2] <= 1e-6, (root, l2)
+        # fp16 forward: the logits carry 1e-3 relative rounding (measured: 1,500-1,900 pixels = 0.09 %, |dmIoU| < 1e-5)
+        assert b <= 0.002 * n_valid and dmb <= 1e-4, (root, b, dmb)
+        assert lb[0] <= 1e-4 and lb[1] <= 1e-4 and lb[2] <= 1e-4, (root, lb)

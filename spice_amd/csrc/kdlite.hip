@@ -497,12 +497,13 @@ __device__ __forceinline__ void kd_grad_regs(const PixStats<VEC> &st, const floa
     }
 }
 
-// Run by ONE workgroup of kKdThreads threads: fixed-order fp64 sum of the per-workgroup partials,
+// Run by ONE workgroup of THREADS threads: fixed-order fp64 sum of the per-workgroup partials,
 // then the scalar epilogue of PixelKDLoss / CrossEntropyLoss / KDLiteLoss.
+template <int THREADS = kKdThreads>
 __device__ __forceinline__ void kd_finalize(const double *partial, int n_blocks, double *totals,
                                             float *out3, float T, float alpha, float bw, int conf) {
-    // thread t owns quantity t % 8 of workgroups t/8, t/8 + 32, ...: coalesced, then an LDS tree
-    __shared__ double fin_red[kKdThreads];
+    // thread t owns quantity t % 8 of workgroups t/8, t/8 + THREADS/8, ...: coalesced, then an LDS tree
+    __shared__ double fin_red[THREADS];
     double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
     const int total = n_blocks * 8;
     int i = threadIdx.x;
@@ -510,17 +511,17 @@ __device__ __forceinline__ void kd_finalize(const double *partial, int n_blocks,
     auto ld = [&](int j) {
         return __longlong_as_double((long long)__hip_atomic_load(pu + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     };
-    for (; i + 3 * kKdThreads < total; i += 4 * kKdThreads) {
-        const double x0 = ld(i), x1 = ld(i + kKdThreads), x2 = ld(i + 2 * kKdThreads), x3 = ld(i + 3 * kKdThreads);
+    for (; i + 3 * THREADS < total; i += 4 * THREADS) {
+        const double x0 = ld(i), x1 = ld(i + THREADS), x2 = ld(i + 2 * THREADS), x3 = ld(i + 3 * THREADS);
         v0 += x0;
         v1 += x1;
         v2 += x2;
         v3 += x3;
     }
-    for (; i < total; i += kKdThreads) v0 += ld(i);
+    for (; i < total; i += THREADS) v0 += ld(i);
     fin_red[threadIdx.x] = (v0 + v1) + (v2 + v3);
     __syncthreads();
-    for (int half = kKdThreads / 2; half >= 8; half >>= 1) {
+    for (int half = THREADS / 2; half >= 8; half >>= 1) {
         if ((int)threadIdx.x < half) fin_red[threadIdx.x] += fin_red[threadIdx.x + half];
         __syncthreads();
     }
@@ -550,6 +551,7 @@ __device__ __forceinline__ void kd_finalize(const double *partial, int n_blocks,
 // and writes the loss.  The sums are stored write-through (agent-scope atomic stores), so no release
 // fence is needed; the storing wave drains them, one lane takes a ticket, and the last arriver
 // acquires before reading.
+template <int THREADS = kKdThreads>
 __device__ __forceinline__ void kd_publish_and_finalize(const KdArgs &a, const double (&out8)[8],
                                                         double (*red)[8]) {
     const int tid = threadIdx.x;
@@ -563,7 +565,7 @@ __device__ __forceinline__ void kd_publish_and_finalize(const KdArgs &a, const d
         __syncthreads();
         if (tid < 8) {
             double v = 0.0;
-            for (int wv = 0; wv < kKdThreads / 64; ++wv) v += red[wv][tid];
+            for (int wv = 0; wv < THREADS / 64; ++wv) v += red[wv][tid];
             __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.main_partial) + (long long)blockIdx.x * 8 + tid,
                                (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -583,7 +585,7 @@ __device__ __forceinline__ void kd_publish_and_finalize(const KdArgs &a, const d
     }
     __syncthreads();
     if (!last_flag) return;
-    kd_finalize(a.main_partial, (int)gridDim.x, a.totals, a.out3, a.T, a.alpha, a.bw, a.conf);
+    kd_finalize<THREADS>(a.main_partial, (int)gridDim.x, a.totals, a.out3, a.T, a.alpha, a.bw, a.conf);
     if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -825,6 +827,9 @@ struct HeadArgs {
     int lds_rows;           // source rows a tile can touch (upper bound, sized on the host)
     int copies, stride;     // layout of the LDS histogram
     ConfTail tail;
+    // the class-innermost form (kdlite_head2_kernel) only:
+    int win_cols;           // source columns staged per row (a multiple of 8; the stage row holds one more)
+    int windowed;           // every tile lies inside one output row: the staged columns follow the tile
 };
 
 struct HeadLane {
@@ -1143,6 +1148,361 @@ __global__ __launch_bounds__(kKdThreads, 2) void kdlite_head_kernel(HeadArgs h) 
 }
 
 
+// ---- the same head, second form: class-innermost LDS image, packed arithmetic, one exponential per logit ----
+//
+// What the form above spends per logit is vector arithmetic, not bytes: four 4-byte LDS reads and an address
+// addition per class plane, the interpolation and the softmax statistics one value at a time, a running maximum
+// whose every change rescales the sums, two quarter-rate exponentials.  This form removes most of it:
+//  * the staged source rows lie [row][column][class] with the class axis padded to CPAD floats (CPAD / 4 odd, so
+//    the sixteen lanes one ds_read_b128 serves together hit sixteen different 16-byte slots): a pixel's four
+//    corners of FOUR classes are four 16-byte reads at immediate offsets, no address arithmetic in the class loop;
+//  * the interpolation and the statistics run on class pairs (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32), with the
+//    fused multiply-adds placed as in upsample_bilinear_kernel: the interpolated logits are the same bits;
+//  * the softmax shift of a pixel is not its running maximum but M = the largest logit of its four source pixels
+//    (a table filled once per tile): an interpolated logit is a convex combination of the corners', so s - M <= 0
+//    up to rounding, and the sums never need rescaling.  Should M lie so far above the pixel's own maximum that
+//    sum exp(s - M) leaves the normal range (or a logit is not finite), the pixel is redone with its exact maximum;
+//  * for the integer temperatures (T = 1..4) exp(s - M) = exp((s - M) / T)^T: one exponential and two packed
+//    multiplications per logit pair instead of two exponentials per logit;
+//  * the label's logit is interpolated once per pixel behind the class loop instead of selected per class.
+// The teacher comes as prepared probabilities (kd_teacher_prepare_kernel).  LOSS = false: arg-max histogram only.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr float kHead2TinySum = 1.0e-20f;   // below it sum exp(s - M) is redone with the exact maximum
+
+__device__ __forceinline__ f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+
+// Bilinear value of two classes: h0 * (w0 * a + w1 * b) + h1 * (w0 * c + w1 * d), the multiply-adds fused as in
+// upsample_bilinear_kernel (fma(w0, a, w1 * b), fma(w0, c, w1 * d), fma(h0, t, h1 * u)).
+__device__ __forceinline__ f32x2_t head2_pair(f32x2_t a, f32x2_t b, f32x2_t c, f32x2_t d, float w0, float w1, float h0,
+                                              float h1) {
+    const f32x2_t t = pk_fma((f32x2_t)(w0), a, (f32x2_t)(w1) * b);
+    const f32x2_t u = pk_fma((f32x2_t)(w0), c, (f32x2_t)(w1) * d);
+    return pk_fma((f32x2_t)(h0), t, (f32x2_t)(h1) * u);
+}
+
+__device__ __forceinline__ float head2_one(const float *stage, int top, int bot, int cpad, int c, float w0, float w1,
+                                           float h0, float h1) {
+    const float a = stage[top + c], b = stage[top + cpad + c], cc = stage[bot + c], d = stage[bot + cpad + c];
+    const float t = __builtin_fmaf(w0, a, w1 * b);
+    const float u = __builtin_fmaf(w0, cc, w1 * d);
+    return __builtin_fmaf(h0, t, h1 * u);
+}
+
+// exp(x)^T from e = exp(x / T) for the integer temperatures.
+template <int TPOW>
+__device__ __forceinline__ f32x2_t pow_t(f32x2_t e) {
+    if constexpr (TPOW == 1) return e;
+    const f32x2_t e2 = e * e;
+    if constexpr (TPOW == 2) return e2;
+    if constexpr (TPOW == 3) return e2 * e;
+    return e2 * e2;
+}
+
+SPICE_ENV_KNOB(knob_head2_threads, "SPICE_HEAD2_THREADS", 0)
+// one output pixel per lane: a tile is as many consecutive pixels of one image as the workgroup has lanes
+static int head2_threads() { return knob_head2_threads() == 256 ? 256 : 512; }
+
+// A lane's pixel over four class planes (c0 .. c0 + 3).  Classes from C on are padding: a large negative FINITE value
+// in the stage (an interpolation weight of exactly zero times -infinity would be a NaN) and probability zero in `tp`,
+// so their exponentials and their terms of sum_c p_c s_c are zero, and they win the arg-max only over a pixel whose
+// real logits are all -infinity (the caller turns such a winner into class 0, the first maximum).
+template <int CPAD, int TPOW, bool LOSS>
+__device__ __forceinline__ void head2_step(const float *top, const float *bot, float w0, float w1, float h0, float h1, int c0,
+                                           float &best, int &arg, float M, float k2, float &zs, float &z1, float &ps,
+                                           const float *tp) {
+    const f32x4_t A = *reinterpret_cast<const f32x4_t *>(top + c0);
+    const f32x4_t B = *reinterpret_cast<const f32x4_t *>(top + CPAD + c0);
+    const f32x4_t Cc = *reinterpret_cast<const f32x4_t *>(bot + c0);
+    const f32x4_t D = *reinterpret_cast<const f32x4_t *>(bot + CPAD + c0);
+    const f32x2_t v01 = head2_pair(A.lo, B.lo, Cc.lo, D.lo, w0, w1, h0, h1);
+    const f32x2_t v23 = head2_pair(A.hi, B.hi, Cc.hi, D.hi, w0, w1, h0, h1);
+    const float v[4] = {v01.x, v01.y, v23.x, v23.y};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        arg = !(v[u] <= best) ? c0 + u : arg;
+        best = __builtin_elementwise_maximum(best, v[u]);   // NaN-propagating
+    }
+    if constexpr (LOSS) {
+        const f32x2_t m2 = (f32x2_t)(M);
+        const f32x2_t x01 = (v01 - m2) * (f32x2_t)(k2);
+        const f32x2_t x23 = (v23 - m2) * (f32x2_t)(k2);
+        f32x2_t e01, e23;
+        e01.x = fast_exp2(x01.x);
+        e01.y = fast_exp2(x01.y);
+        e23.x = fast_exp2(x23.x);
+        e23.y = fast_exp2(x23.y);
+        const f32x2_t es = e01 + e23;
+        zs += es.x + es.y;
+        if constexpr (TPOW > 1) {
+            const f32x2_t ep = pow_t<TPOW>(e01) + pow_t<TPOW>(e23);
+            z1 += ep.x + ep.y;
+        }
+        ps = __builtin_fmaf(tp[c0], v[0], ps);   // sum_c p_c s_c
+        ps = __builtin_fmaf(tp[c0 + 1], v[1], ps);
+        ps = __builtin_fmaf(tp[c0 + 2], v[2], ps);
+        ps = __builtin_fmaf(tp[c0 + 3], v[3], ps);
+    }
+}
+
+// One output pixel per lane, workgroups of 512.  What hides the memory's latency is the teacher data in flight per
+// compute unit; a lane requests the probabilities of ALL its classes (a register each) at the start of its tile, before
+// the tile's source rows are staged, so they arrive while the workgroup stages and the class loop never waits for
+// memory.  A lane's state is small enough for four waves per SIMD: two workgroups = 1024 pixels x C classes x 4 bytes
+// (86 KB at 21 classes) requested per compute unit.
+template <int CPAD, int TPOW, bool LOSS, int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void kdlite_head2_kernel(HeadArgs h) {
+    extern __shared__ float4 head_lds_raw[];
+    const KdArgs &a = h.kd;
+    const int C = a.C;
+    const int WC = h.win_cols + 1;                  // staged columns per row: the window and its right neighbour
+    const int n_src = h.lds_rows * WC;
+    float *stage = reinterpret_cast<float *>(head_lds_raw);                 // [lds_rows][WC][CPAD] fp32
+    float *smax = stage + n_src * CPAD;                                      // [lds_rows][WC]: largest logit of a source pixel
+    unsigned *lds_hist = reinterpret_cast<unsigned *>(smax + ((n_src + 3) & ~3));
+    __shared__ double red[THREADS / 64][8];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < h.copies * h.stride; i += THREADS) lds_hist[i] = 0;
+    if (CPAD > C) {   // the padding classes, once (the tiles write the real classes only)
+        for (int j = tid; j < n_src; j += THREADS)
+            for (int c = C; c < CPAD; ++c) stage[j * CPAD + c] = kNegFill;
+    }
+    unsigned *hist = lds_hist + (tid & (h.copies - 1)) * h.stride;
+    const float k2 = a.invT * kLog2e;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int bad = 0;
+    const int HW = (int)a.HW;
+    const int W = a.W;
+    const int tiles_per_img = (HW + THREADS - 1) / THREADS;
+    const int n_tiles = (int)a.N * tiles_per_img;
+    const int chunks_per_row = h.win_cols >> 3;   // 8 halves = 16 bytes
+    const float inv_c = 1.0f / (float)C;
+    const float inv_per_row = 1.0f / (float)chunks_per_row;
+    const float inv_w = 1.0f / (float)W;
+    typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+    // A lane's column: the same in every tile when a tile is a whole number of output rows (worked out once).
+    const bool same_columns = (THREADS % W) == 0;
+    int xoff = 0;            // x0 * CPAD: the column part of the corner's offset, before the window's start is taken off
+    float w0 = 0.f, w1 = 0.f;
+    auto column = [&](int ox) {
+        const float sx = src_index(h.scale_w, ox, h.align_corners);
+        const int x0 = min((int)sx, h.in_w - 1);
+        w1 = sx - (float)x0;
+        w0 = 1.0f - w1;
+        xoff = x0 * CPAD;
+    };
+    const int lane_row = (int)(((float)tid + 0.5f) * inv_w);     // exact: the numbers stay far below 2^22
+    const int lane_col = tid - lane_row * W;
+    if (same_columns) column(lane_col);
+
+    // a tile's source rows: where they lie
+    struct Rows {
+        int n, y_lo, y_hi, x_lo, px_first, px_last, oy_first;
+    };
+    auto rows_of = [&](int tile) {
+        Rows q;
+        q.n = tile / tiles_per_img;
+        q.px_first = (tile - q.n * tiles_per_img) * THREADS;
+        q.px_last = min(q.px_first + THREADS, HW) - 1;
+        q.oy_first = q.px_first / W;
+        q.y_lo = (int)src_index(h.scale_h, q.oy_first, h.align_corners);
+        const int y_last = (int)src_index(h.scale_h, q.px_last / W, h.align_corners);
+        q.y_hi = min(min(y_last + 1, h.in_h - 1), q.y_lo + h.lds_rows - 1);
+        q.x_lo = 0;
+        if (h.windowed)
+            q.x_lo = min(((int)src_index(h.scale_w, q.px_first - q.oy_first * W, h.align_corners)) & ~7, h.in_w - h.win_cols);
+        return q;
+    };
+    // chunk number -> (class, row, 8-column piece); exact while the numbers stay far below 2^22 (the host bounds the stage)
+    auto load_chunk = [&](const __half *src, int i) {
+        const int k = (int)(((float)i + 0.5f) * inv_c);
+        const int c = i - k * C;
+        const int rr = (int)(((float)k + 0.5f) * inv_per_row);
+        const int kc = k - rr * chunks_per_row;
+        return *reinterpret_cast<const f16x8_t *>(src + ((long long)c * h.in_h + rr) * h.in_w + kc * 8);
+    };
+    auto deposit_chunk = [&](int i, const f16x8_t &piece) {
+        const int k = (int)(((float)i + 0.5f) * inv_c);
+        const int c = i - k * C;
+        const int rr = (int)(((float)k + 0.5f) * inv_per_row);
+        const int kc = k - rr * chunks_per_row;
+        float *d = stage + (rr * WC + kc * 8) * CPAD + c;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) d[m * CPAD] = (float)piece[m];
+        if (kc == chunks_per_row - 1) d[8 * CPAD] = (float)piece[7];   // right neighbour of the last column
+    };
+    constexpr int NPRE = 1024 / THREADS;   // chunks per lane requested one tile ahead (1024 per workgroup)
+    f16x8_t pre[NPRE];
+    auto request = [&](const Rows &q) {
+        const __half *src = h.low + ((long long)q.n * C * h.in_h + q.y_lo) * h.in_w + q.x_lo;
+        const int total = C * (q.y_hi - q.y_lo + 1) * chunks_per_row;
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = tid + j * THREADS;
+            if (i < total) pre[j] = load_chunk(src, i);
+        }
+    };
+    Rows cur = rows_of((int)blockIdx.x);
+    if ((int)blockIdx.x < n_tiles) request(cur);
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int n = cur.n;
+        const int px_first = cur.px_first;
+        const int r = px_first + tid;   // the lane's pixel inside the image
+        const bool live = r < HW;
+        // everything the lane needs from memory is requested first: its teacher probabilities, label, entropy term
+        float tp[CPAD];
+        long long lab = -1;
+        float hn = 0.f;
+        if constexpr (LOSS) {
+            // The image's teacher planes through a buffer descriptor: a load is ONE instruction (the plane's offset a
+            // scalar operand, the lane's 32-bit byte offset the vector one, no address arithmetic in vector registers),
+            // and a class past the last lies outside the buffer, which reads as zero without touching memory -
+            // probability zero, no branch.
+            const __amdgpu_buffer_rsrc_t planes = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(a.t + (long long)n * C * a.HW), 0, C * HW * 4, 0x00020000);
+            const int rb = (live ? r : 0) * 4;
+#ifndef SPICE_HEAD2_TIMING_NO_TEACHER
+#pragma unroll
+            for (int c = 0; c < CPAD; ++c)
+                tp[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(planes, rb, c * HW * 4, 2 /* non-temporal */));
+#else
+#pragma unroll
+            for (int c = 0; c < CPAD; ++c) tp[c] = 0.01f * (float)c;
+#endif
+            if (live) hn = __builtin_nontemporal_load(h.hneg + (long long)n * a.HW + r);
+        }
+        if (live) lab = a.labels[(long long)n * a.HW + r];
+
+        const int oy_first = cur.oy_first, y_lo = cur.y_lo, y_hi = cur.y_hi, x_lo = cur.x_lo;
+        const int rows = y_hi - y_lo + 1;
+        __syncthreads();   // whoever still reads the previous tile's rows (first time: the cleared histogram, the padding)
+        {
+            // The tile's source chunks were requested while the previous tile was worked on (the first tile's before
+            // the loop): converted and stored now.  Chunk i = (k, c) with the class fastest: a wave's stores fall on
+            // consecutive banks.
+            const int total = C * rows * chunks_per_row;
+#pragma unroll
+            for (int j = 0; j < NPRE; ++j) {
+                const int i = tid + j * THREADS;
+                if (i < total) deposit_chunk(i, pre[j]);
+            }
+            if (total > NPRE * THREADS) {   // a stage larger than the chunks held ahead: the rest straight from memory
+                const __half *src = h.low + ((long long)n * C * h.in_h + y_lo) * h.in_w + x_lo;
+                for (int i = tid + NPRE * THREADS; i < total; i += THREADS) deposit_chunk(i, load_chunk(src, i));
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < n_tiles) {   // the next tile's source chunks: on their way while this tile is worked on
+            cur = rows_of(tile + (int)gridDim.x);
+            request(cur);
+        }
+        if constexpr (LOSS) {
+            for (int j = tid; j < rows * WC; j += THREADS) {
+                const f32x4_t *p = reinterpret_cast<const f32x4_t *>(stage + j * CPAD);
+                float m = kNegFill;
+#pragma unroll
+                for (int s4 = 0; s4 < CPAD / 4; ++s4) {
+                    const f32x4_t x = p[s4];
+                    m = fmaxf(fmaxf(m, fmaxf(x.x, x.y)), fmaxf(x.z, x.w));
+                }
+                smax[j] = m;
+            }
+            __syncthreads();
+        }
+        if (!live) continue;
+        int oy;
+        if (same_columns) {
+            oy = oy_first + lane_row;
+        } else {
+            oy = (HW < (1 << 22)) ? (int)(((float)r + 0.5f) * inv_w) : r / W;
+            column(r - oy * W);
+        }
+        float h0, h1;
+        int jt, jb;   // the corner's source pixel in the stage, upper and lower row
+        {
+            const float sy = src_index(h.scale_h, oy, h.align_corners);
+            const int y0 = min((int)sy, y_hi);
+            const int y1 = min(y0 + 1, y_hi);
+            h1 = sy - (float)y0;
+            h0 = 1.0f - h1;
+            const int jc = xoff / CPAD - x_lo;   // CPAD is a constant: a multiplication and a shift
+            jt = (y0 - y_lo) * WC + jc;
+            jb = (y1 - y_lo) * WC + jc;
+        }
+        const float *top = stage + jt * CPAD, *bot = stage + jb * CPAD;
+        float best = -__builtin_inff();
+        int arg = 0;
+        float zs = 0.f, z1 = 0.f, ps = 0.f, M = 0.f;
+        if constexpr (LOSS) M = fmaxf(fmaxf(smax[jt], smax[jt + 1]), fmaxf(smax[jb], smax[jb + 1]));
+#pragma unroll
+        for (int c0 = 0; c0 < CPAD; c0 += 4) {
+            if (c0 >= C) break;   // wave-uniform
+            head2_step<CPAD, TPOW, LOSS>(top, bot, w0, w1, h0, h1, c0, best, arg, M, k2, zs, z1, ps, tp);
+        }
+        arg = arg >= C ? 0 : arg;   // a padding class wins only where every real logit is -infinity: class 0
+        if (best != best) {
+            // a NaN among the pixel's logits: the exact class-by-class walk (a NaN is the maximum, the first one wins)
+            float bv = head2_one(stage, jt * CPAD, jb * CPAD, CPAD, 0, w0, w1, h0, h1);
+            arg = 0;
+            for (int c = 1; c < C; ++c) {
+                const float v = head2_one(stage, jt * CPAD, jb * CPAD, CPAD, c, w0, w1, h0, h1);
+                const bool take = (v > bv) || (v != v && bv == bv);
+                bv = take ? v : bv;
+                arg = take ? c : arg;
+            }
+        }
+#ifdef SPICE_HEAD2_TIMING_NO_TAIL
+        acc[0] += best + (float)arg + zs + z1 + ps;
+        continue;
+#endif
+        const int id = (lab >= 0 && lab < C) ? (int)lab : ((LOSS && lab == a.ignore_index) ? -1 : -2);
+        if (id >= 0) atomicAdd(&hist[id * C + arg], 1u);
+        if constexpr (!LOSS) continue;
+
+        float Zs = zs, Z1 = TPOW > 1 ? z1 : zs, ms = M;
+        if (!(Z1 > kHead2TinySum) || !(Zs < 3.0e38f)) {
+            // M far above the pixel's own logits, or a logit that is not finite: the sums about the exact running
+            // maximum, as the first form keeps them
+            Zs = Z1 = 0.f;
+            ms = kNegFill;
+            for (int c = 0; c < C; ++c) {
+                const float v = head2_one(stage, jt * CPAD, jb * CPAD, CPAD, c, w0, w1, h0, h1);
+                const float mn = fmaxf(ms, v);
+                const float ds = ms - mn;
+                Zs = Zs * fast_exp2(ds * k2) + fast_exp2((v - mn) * k2);
+                Z1 = Z1 * fast_exp2(ds * kLog2e) + fast_exp2((v - mn) * kLog2e);
+                ms = mn;
+            }
+        }
+        if (id == -2) ++bad;
+        const float sy = id >= 0 ? head2_one(stage, jt * CPAD, jb * CPAD, CPAD, id, w0, w1, h0, h1) : 0.f;
+        const float kl = hn + a.invT * (ms - ps) + fast_ln(Zs);
+        const float nll = fast_ln(Z1) - (sy - ms);
+        const float wy = (id >= 0) ? (a.class_w ? a.class_w[id] : 1.f) : 0.f;
+        if (id != -1) {
+            acc[0] += kl;
+            acc[1] += 1.0;
+        }
+        if (id >= 0) {
+            acc[2] += wy * nll;
+            acc[3] += wy;
+        }
+    }
+    if (LOSS && bad) atomicAdd(reinterpret_cast<unsigned long long *>(a.bad), (unsigned long long)bad);
+    __syncthreads();   // (a workgroup without a tile has not passed a barrier since it cleared the histogram)
+    conf_finish<THREADS>(lds_hist, h.copies, h.stride, C * C, 0u, h.tail);
+    if constexpr (!LOSS) return;
+    double out8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out8[k] = k < 4 ? acc[k % 4] : 0.0;
+    __syncthreads();
+    kd_publish_and_finalize<THREADS>(a, out8, red);
+}
+
+
 __global__ __launch_bounds__(256) void scale_inplace_kernel(float *x, int64_t n, const float *scale) {
     const float s = *scale;
     if (s == 1.0f) return;
@@ -1350,10 +1710,22 @@ extern "C" int spice_kd_teacher_prepare(const float *teacher, int64_t n, int64_t
 namespace spice {
 
 // Geometry, LDS stage and grid shared by the head kernel's entry points.  `params` and the loss workspace are
-// absent for the arg-max-only form.  Returns SPICE_OK with `ha`, `blocks`, `lds_bytes` and `chunks` set.
+// absent for the arg-max-only form.  `form` 2 sizes the class-innermost stage of kdlite_head2_kernel (returns
+// SPICE_ERR_UNSUPPORTED where that form does not apply: more than 28 classes, a stage beyond its LDS budget), `form` 1
+// the plane-major stage of kdlite_head_kernel.  Returns SPICE_OK with `ha`, `blocks`, `lds_bytes` and `chunks` set.
+SPICE_ENV_KNOB(knob_head_form, "SPICE_HEAD_FORM", 0)   // 1 = always the first form (A/B measurements)
+
+constexpr size_t kHead2MaxLdsBytes = 63 * 1024;   // with the kernel's static LDS within the 64 KiB a launch may ask for unannounced
+
+static int head2_cpad(int64_t c) {   // the class axis padded to a multiple of 4 floats whose quarter is odd
+    int cpad = (int)((c + 3) / 4) * 4;
+    if ((cpad / 4) % 2 == 0) cpad += 4;
+    return cpad;
+}
+
 static int head_prepare(HeadArgs &ha, const void *low, const int64_t *labels, int64_t n, int64_t c, int64_t in_h,
                         int64_t in_w, int64_t h, int64_t w, int32_t align_corners, float scale_h, float scale_w,
-                        int64_t *conf, void *conf_workspace, size_t conf_workspace_bytes, bool loss, int64_t &blocks,
+                        int64_t *conf, void *conf_workspace, size_t conf_workspace_bytes, bool loss, int form, int64_t &blocks,
                         size_t &lds_bytes, int64_t &chunks) {
     if (!conf || !conf_workspace || !low || !labels) return SPICE_ERR_ARG;
     if (n < 1 || c < 1 || h < 1 || w < 1 || in_h < 1 || in_w < 1) return SPICE_ERR_ARG;
@@ -1378,32 +1750,82 @@ static int head_prepare(HeadArgs &ha, const void *low, const int64_t *labels, in
         ha.scale_w = scale_w > 0.0f ? 1.0f / scale_w : static_cast<float>(in_w) / static_cast<float>(w);
     }
     if (ha.scale_h > 1.0f || ha.scale_w > 1.0f) return SPICE_ERR_UNSUPPORTED;
-    // output rows a tile of 1024 consecutive pixels can touch, and the source rows under them: the
-    // span of the upper rows, the lower neighbour of the last, one more where the truncations fall
-    const int64_t tile_px = (int64_t)kKdThreads * 4;
+    // output rows a tile of consecutive pixels (1024 in the first form, 512 in the second) can touch, and the source
+    // rows under them: the span of the upper rows, the lower neighbour of the last, one more where the truncations fall
+    const int64_t tile_px = form == 2 ? (int64_t)head2_threads() : (int64_t)kKdThreads * 4;
     int64_t out_rows = (tile_px % w == 0) ? tile_px / w : tile_px / w + 2;
     if (out_rows > h) out_rows = h;
-    int64_t lds_rows = (int64_t)((float)(out_rows - 1) * ha.scale_h + 1e-3f) + 3;
+    const bool one_row = (w % tile_px == 0);   // every tile lies inside one output row
+    int64_t lds_rows = one_row ? 2 : (int64_t)((float)(out_rows - 1) * ha.scale_h + 1e-3f) + 3;
     if (lds_rows > in_h) lds_rows = in_h;
     ha.lds_rows = (int)lds_rows;
-    const ConfGeom g = conf_geom((int)c);
+    ConfGeom g = conf_geom((int)c);
+    int max_per_cu = loss ? 2 : 3;
+    if (form == 2) {
+        if (c > 28 || (int64_t)head2_cpad(c) * hw * 4 >= ((int64_t)1 << 31)) return SPICE_ERR_UNSUPPORTED;   // an image's planes as one buffer
+        const int cpad = head2_cpad(c);
+        // the source columns under a tile: whole rows, or (a tile inside one output row) the columns under its
+        // pixels, from a multiple of 8 on
+        int64_t win = in_w;
+        ha.windowed = 0;
+        if (one_row) {
+            // first to last left neighbour: the whole part of (tile - 1) * scale, one more where the fractions carry;
+            // then the last one's right neighbour
+            const int64_t span = (int64_t)((float)(tile_px - 1) * ha.scale_w + 1e-3f) + 3;
+            const int64_t need = (span + 7 + 7) / 8 * 8;
+            if (need < in_w) {
+                win = need;
+                ha.windowed = 1;
+            }
+        }
+        ha.win_cols = (int)win;
+        const size_t src_px = (size_t)lds_rows * (win + 1);
+        const size_t stage_bytes = src_px * cpad * sizeof(float) + ((src_px + 3) / 4 * 4) * sizeof(float);
+        // histogram copies: as many as leave room for three workgroups per compute unit
+        size_t hist_bytes = (size_t)g.copies * g.stride * 4;
+        while (g.copies > 2 && (size_t)(3 * (512 / head2_threads())) * (stage_bytes + hist_bytes + 512) > kLdsPerCu) {
+            g.copies >>= 1;
+            hist_bytes = (size_t)g.copies * g.stride * 4;
+        }
+        lds_bytes = stage_bytes + hist_bytes;
+        if (lds_bytes > kHead2MaxLdsBytes) return SPICE_ERR_UNSUPPORTED;
+        chunks = c * lds_rows * (win / 8);
+        if (chunks >= (1 << 20)) return SPICE_ERR_UNSUPPORTED;   // the float reciprocals that split a chunk number stay exact
+        max_per_cu = (int)(kLdsPerCu / (lds_bytes + 512));
+        // resident workgroups per compute unit: 512 lanes at four waves per SIMD (the loss form's registers) are two,
+        // the arg-max form's registers allow three
+        const int reg_limit = (loss ? 2 : 3) * (512 / head2_threads());
+        if (max_per_cu > reg_limit) max_per_cu = reg_limit;
+        if (max_per_cu < 1) max_per_cu = 1;
+    } else {
+        ha.win_cols = (int)in_w;
+        ha.windowed = 0;
+        if (one_row) ha.lds_rows = (int)(lds_rows = (lds_rows + 1 > in_h ? in_h : lds_rows + 1));   // the first form's own bound
+        const size_t stage_bytes = (size_t)c * lds_rows * (in_w + 1) * sizeof(float);
+        lds_bytes = stage_bytes + (size_t)g.copies * g.stride * 4;
+        // the kernel's own static LDS (partial sums, flags) comes on top of the dynamic part
+        if (lds_bytes + 1024 > kHeadMaxLdsBytes) return SPICE_ERR_UNSUPPORTED;
+        chunks = c * lds_rows * (in_w / 8);   // 16-byte source chunks of a tile
+        if (chunks > 8 * kKdThreads) return SPICE_ERR_UNSUPPORTED;
+    }
     ha.copies = g.copies;
     ha.stride = g.stride;
-    const size_t stage_bytes = (size_t)c * lds_rows * (in_w + 1) * sizeof(float);
-    lds_bytes = stage_bytes + (size_t)g.copies * g.stride * 4;
-    if (lds_bytes > kHeadMaxLdsBytes) return SPICE_ERR_UNSUPPORTED;
-    chunks = c * lds_rows * (in_w / 8);   // 16-byte source chunks of a tile
-    if (chunks > 8 * kKdThreads) return SPICE_ERR_UNSUPPORTED;
 
-    const int64_t tiles = n * ceil_div(hw / 4, kKdThreads);
+    const int64_t tiles = n * ceil_div(hw, tile_px);
     if (tiles > INT32_MAX) return SPICE_ERR_UNSUPPORTED;
     // workgroups per compute unit, each looping over its tiles.  Measured on MI355X at [8,21,128,128] -> 512 x 512
-    // (HIP events): the loss forms 109 / 90 / 92 / 95 us with 1 / 2 / 3 / 4 (their registers allow two waves per SIMD),
-    // the arg-max-only form 61 / 45 / 40 / 47 us
-    const long per_cu = knob_head_blocks_per_cu() >= 1 ? knob_head_blocks_per_cu() : (loss ? 2 : 3);
+    // (HIP events), first form: the loss forms 109 / 90 / 92 / 95 us with 1 / 2 / 3 / 4 (their registers allow two waves
+    // per SIMD), the arg-max-only form 61 / 45 / 40 / 47 us
+    const long per_cu = knob_head_blocks_per_cu() >= 1 ? knob_head_blocks_per_cu() : max_per_cu;
     blocks = tiles;
-    if (blocks > per_cu * device_cu_count()) blocks = per_cu * device_cu_count();
-    if (blocks > kConfMaxBlocks) blocks = kConfMaxBlocks;   // also within kKdMaxBlocks
+    int64_t resident = per_cu * device_cu_count();
+    if (resident > kConfMaxBlocks) resident = kConfMaxBlocks;   // also within kKdMaxBlocks
+    if (blocks > resident) {
+        // every workgroup the same number of tiles (the last ones one fewer): 2048 tiles on 768 resident workgroups
+        // are 683 workgroups of three, not 768 of which two thirds take three
+        const int64_t per_wg = ceil_div(tiles, resident);
+        blocks = form == 2 ? ceil_div(tiles, per_wg) : resident;
+    }
 
     KdArgs &a = ha.kd;
     a = KdArgs{};
@@ -1417,6 +1839,43 @@ static int head_prepare(HeadArgs &ha, const void *low, const int64_t *labels, in
     a.ignore_index = 255;
     a.T = a.invT = 1.0f;
     ha.tail = conf_tail(conf_workspace, conf, nullptr, (int)blocks);
+    return SPICE_OK;
+}
+
+template <int CPAD, bool LOSS, int THREADS>
+static void head2_launch_tt(int tpow, dim3 grid, size_t lds_bytes, hipStream_t st, const HeadArgs &ha) {
+    const dim3 block(THREADS);
+    if constexpr (!LOSS) {
+        hipLaunchKernelGGL((kdlite_head2_kernel<CPAD, 1, false, THREADS>), grid, block, lds_bytes, st, ha);
+    } else {
+        switch (tpow) {
+            case 1: hipLaunchKernelGGL((kdlite_head2_kernel<CPAD, 1, true, THREADS>), grid, block, lds_bytes, st, ha); break;
+            case 2: hipLaunchKernelGGL((kdlite_head2_kernel<CPAD, 2, true, THREADS>), grid, block, lds_bytes, st, ha); break;
+            case 3: hipLaunchKernelGGL((kdlite_head2_kernel<CPAD, 3, true, THREADS>), grid, block, lds_bytes, st, ha); break;
+            default: hipLaunchKernelGGL((kdlite_head2_kernel<CPAD, 4, true, THREADS>), grid, block, lds_bytes, st, ha); break;
+        }
+    }
+}
+
+template <int CPAD, bool LOSS>
+static void head2_launch_t(int tpow, dim3 grid, size_t lds_bytes, hipStream_t st, const HeadArgs &ha) {
+    if (head2_threads() == 256)
+        head2_launch_tt<CPAD, LOSS, 256>(tpow, grid, lds_bytes, st, ha);
+    else
+        head2_launch_tt<CPAD, LOSS, 512>(tpow, grid, lds_bytes, st, ha);
+}
+
+template <bool LOSS>
+static int head2_launch(int cpad, int tpow, int64_t blocks, size_t lds_bytes, hipStream_t st, const HeadArgs &ha) {
+    const dim3 grid((unsigned)blocks);
+    switch (cpad) {
+        case 4: head2_launch_t<4, LOSS>(tpow, grid, lds_bytes, st, ha); break;
+        case 12: head2_launch_t<12, LOSS>(tpow, grid, lds_bytes, st, ha); break;
+        case 20: head2_launch_t<20, LOSS>(tpow, grid, lds_bytes, st, ha); break;
+        case 28: head2_launch_t<28, LOSS>(tpow, grid, lds_bytes, st, ha); break;
+        default: return SPICE_ERR_UNSUPPORTED;
+    }
+    SPICE_LAUNCH_CHECK();
     return SPICE_OK;
 }
 
@@ -1438,8 +1897,17 @@ extern "C" int spice_sweep_head_f16(const void *low, const float *teacher, const
     HeadArgs ha;
     int64_t blocks = 0, chunks = 0;
     size_t lds_bytes = 0;
-    const int rc = head_prepare(ha, low, labels, n, c, in_h, in_w, h, w, align_corners, scale_h, scale_w, conf,
-                                conf_workspace, conf_workspace_bytes, true, blocks, lds_bytes, chunks);
+    // the class-innermost form takes the prepared teacher at the integer temperatures
+    const float T = params->temperature;
+    const int tpow = (T == 1.0f) ? 1 : (T == 2.0f) ? 2 : (T == 3.0f) ? 3 : (T == 4.0f) ? 4 : 0;
+    int form = (teacher_hneg != nullptr && tpow != 0 && knob_head_form() != 1) ? 2 : 1;
+    int rc = head_prepare(ha, low, labels, n, c, in_h, in_w, h, w, align_corners, scale_h, scale_w, conf,
+                          conf_workspace, conf_workspace_bytes, true, form, blocks, lds_bytes, chunks);
+    if (rc == SPICE_ERR_UNSUPPORTED && form == 2) {
+        form = 1;
+        rc = head_prepare(ha, low, labels, n, c, in_h, in_w, h, w, align_corners, scale_h, scale_w, conf,
+                          conf_workspace, conf_workspace_bytes, true, form, blocks, lds_bytes, chunks);
+    }
     if (rc != SPICE_OK) return rc;
     ha.hneg = teacher_hneg;
     char *ws = static_cast<char *>(kd_workspace);
@@ -1461,6 +1929,7 @@ extern "C" int spice_sweep_head_f16(const void *low, const float *teacher, const
     a.coef_kd = 1.0f - params->alpha;
     a.conf = 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (form == 2) return head2_launch<true>(head2_cpad(c), tpow, blocks, lds_bytes, st, ha);
     const dim3 grid((unsigned)blocks), block(kKdThreads);
     const bool probs = teacher_hneg != nullptr;
     if (chunks > 4 * kKdThreads) {
@@ -1485,10 +1954,17 @@ extern "C" int spice_upsample_argmax_confusion_f16(const void *low, const int64_
     HeadArgs ha;
     int64_t blocks = 0, chunks = 0;
     size_t lds_bytes = 0;
-    const int rc = head_prepare(ha, low, labels, n, c, in_h, in_w, h, w, align_corners, scale_h, scale_w, conf,
-                                conf_workspace, conf_workspace_bytes, false, blocks, lds_bytes, chunks);
+    int form = knob_head_form() != 1 ? 2 : 1;
+    int rc = head_prepare(ha, low, labels, n, c, in_h, in_w, h, w, align_corners, scale_h, scale_w, conf,
+                          conf_workspace, conf_workspace_bytes, false, form, blocks, lds_bytes, chunks);
+    if (rc == SPICE_ERR_UNSUPPORTED && form == 2) {
+        form = 1;
+        rc = head_prepare(ha, low, labels, n, c, in_h, in_w, h, w, align_corners, scale_h, scale_w, conf,
+                          conf_workspace, conf_workspace_bytes, false, form, blocks, lds_bytes, chunks);
+    }
     if (rc != SPICE_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (form == 2) return head2_launch<false>(head2_cpad(c), 1, blocks, lds_bytes, st, ha);
     const dim3 grid((unsigned)blocks), block(kKdThreads);
     if (chunks > 4 * kKdThreads)
         hipLaunchKernelGGL((kdlite_head_kernel<4, 8, false, false>), grid, block, lds_bytes, st, ha);

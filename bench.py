@@ -782,15 +782,22 @@ def main():
         prepared = sweep._teacher_prepared is not None   # teacher's softmax taken once per sweep: + 4 bytes per pixel
         kd_bytes = (BATCH * CLASSES * (SIZE // 4) * (SIZE // 4) * 2 + BATCH * SIZE * SIZE * (CLASSES * 4 + 8)
                     + (BATCH * SIZE * SIZE * 4 if prepared else 0))
-        kd_kernel = (f"spice::kdlite_head_kernel<4,4,{str(prepared).lower()},true> (one launch per candidate: bilinear "
+        # the class-innermost form takes the prepared teacher at the integer temperatures (SPICE_HEAD_FORM=1: the first form)
+        second_form = prepared and os.environ.get("SPICE_HEAD_FORM", "0") != "1"
+        if second_form:
+            kd_key = "spice::kdlite_head2_kernel<28, 4, true, 512>"
+            kd_name = "spice::kdlite_head2_kernel<28,4,true,512>"
+        else:
+            kd_key = f"spice::kdlite_head_kernel<4, 4, {str(prepared).lower()}, true>"
+            kd_name = f"spice::kdlite_head_kernel<4,4,{str(prepared).lower()},true>"
+        kd_kernel = (f"{kd_name} (one launch per candidate: bilinear "
                      "up-sampling of the head's fp16 logits + KD-Lite loss + arg-max + confusion histogram"
                      + (", against the teacher's probabilities prepared once per sweep" if prepared else "") +
                      "; replaces upsample_bilinear_kernel, argmax_confusion_kernel and kdlite_main_kernel = 128 us "
                      "and 550 MB of traffic per candidate)")
-        kd_key = f"spice::kdlite_head_kernel<4, 4, {str(prepared).lower()}, true>"
-        kd_note = ("bound by vector arithmetic, not by memory: " + ("two" if prepared else "three") + " exponentials "
-                   "(quarter rate) and the six-operation interpolation per logit; the loss kernel alone on full-size "
-                   "logits reaches 0.71 (`kernels` table)")
+        kd_note = ("bound by vector arithmetic and by the dependent trips of its two tails (per-workgroup totals -> ticket -> "
+                   "last arriver), not by memory: an exponential, the six-operation interpolation and the arg-max per logit; "
+                   "the loss kernel alone on full-size logits reaches 0.66-0.71 (`kernels` table)")
     else:
         kd_bytes = BATCH * SIZE * SIZE * (2 * CLASSES * 4 + 8)
         kd_kernel = "spice::kdlite_main_kernel<4,false,false,false> (one launch per spice_kdlite_forward call)"

@@ -60,6 +60,30 @@ struct ConfTail {
     int group;
 };
 
+// Run by the last arriver of a ticket group: the group's rows of the table (agent-scope loads: never a stale
+// cached line), `members` of them from row `first` on, summed per bin and added to the caller's matrix.  Eight rows
+// are requested at a time: the loads of a bin are independent, and what this costs is round trips, not bytes.
+template <int THREADS>
+__device__ __forceinline__ void conf_fold_group(const ConfTail &t, int first, int members, int bins) {
+    const int tid = threadIdx.x;
+    for (int b = tid; b < bins; b += THREADS) {
+        const unsigned *col = t.partial + (int64_t)first * bins + b;
+        unsigned long long s = 0;
+        int m = 0;
+        for (; m + 7 < members; m += 8) {
+            unsigned v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                v[k] = __hip_atomic_load(col + (int64_t)(m + k) * bins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; m < members; ++m)
+            s += __hip_atomic_load(col + (int64_t)m * bins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s) atomicAdd(t.conf + b, s);
+    }
+}
+
 // Common end of the histogram kernels (workgroups of THREADS threads).  On entry every LDS atomic of the workgroup has been
 // issued (the caller has not synchronised yet).  The totals of the privatised copies go to this
 // workgroup's row of the table as agent-scope stores (write-through, so no release fence), one
@@ -98,21 +122,7 @@ __device__ __forceinline__ void conf_finish(const unsigned *lds_hist, int copies
     }
     __syncthreads();
     if (!last_flag) return;
-    for (int b = tid; b < bins; b += THREADS) {
-        const unsigned *col = t.partial + (int64_t)first * bins + b;
-        unsigned long long s = 0;
-        int m = 0;
-        for (; m + 3 < members; m += 4) {
-            const unsigned v0 = __hip_atomic_load(col + (int64_t)m * bins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned v1 = __hip_atomic_load(col + (int64_t)(m + 1) * bins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned v2 = __hip_atomic_load(col + (int64_t)(m + 2) * bins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned v3 = __hip_atomic_load(col + (int64_t)(m + 3) * bins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s += (unsigned long long)v0 + v1 + v2 + v3;
-        }
-        for (; m < members; ++m)
-            s += __hip_atomic_load(col + (int64_t)m * bins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (s) atomicAdd(t.conf + b, s);
-    }
+    conf_fold_group<THREADS>(t, first, members, bins);
 }
 
 // The scratch area (caller workspace or a static array) seen as the table, the tickets and the counter.

@@ -1210,8 +1210,8 @@ static int head2_threads() { return knob_head2_threads() == 256 ? 256 : 512; }
 // real logits are all -infinity (the caller turns such a winner into class 0, the first maximum).
 template <int CPAD, int TPOW, bool LOSS>
 __device__ __forceinline__ void head2_step(const float *top, const float *bot, float w0, float w1, float h0, float h1, int c0,
-                                           float &best, int &arg, float M, float k2, float &zs, float &z1, float &ps,
-                                           const float *tp) {
+                                           float &best, int &arg, float mk, float k2, f32x2_t &zs, f32x2_t &z1, f32x2_t &ps,
+                                           const f32x2_t *tp) {
     const f32x4_t A = *reinterpret_cast<const f32x4_t *>(top + c0);
     const f32x4_t B = *reinterpret_cast<const f32x4_t *>(top + CPAD + c0);
     const f32x4_t Cc = *reinterpret_cast<const f32x4_t *>(bot + c0);
@@ -1225,24 +1225,18 @@ __device__ __forceinline__ void head2_step(const float *top, const float *bot, f
         best = __builtin_elementwise_maximum(best, v[u]);   // NaN-propagating
     }
     if constexpr (LOSS) {
-        const f32x2_t m2 = (f32x2_t)(M);
-        const f32x2_t x01 = (v01 - m2) * (f32x2_t)(k2);
-        const f32x2_t x23 = (v23 - m2) * (f32x2_t)(k2);
+        // (s - M) / T in base-2 units as one multiply-add: s * k2 - M * k2
+        const f32x2_t x01 = pk_fma(v01, (f32x2_t)(k2), (f32x2_t)(mk));
+        const f32x2_t x23 = pk_fma(v23, (f32x2_t)(k2), (f32x2_t)(mk));
         f32x2_t e01, e23;
         e01.x = fast_exp2(x01.x);
         e01.y = fast_exp2(x01.y);
         e23.x = fast_exp2(x23.x);
         e23.y = fast_exp2(x23.y);
-        const f32x2_t es = e01 + e23;
-        zs += es.x + es.y;
-        if constexpr (TPOW > 1) {
-            const f32x2_t ep = pow_t<TPOW>(e01) + pow_t<TPOW>(e23);
-            z1 += ep.x + ep.y;
-        }
-        ps = __builtin_fmaf(tp[c0], v[0], ps);   // sum_c p_c s_c
-        ps = __builtin_fmaf(tp[c0 + 1], v[1], ps);
-        ps = __builtin_fmaf(tp[c0 + 2], v[2], ps);
-        ps = __builtin_fmaf(tp[c0 + 3], v[3], ps);
+        zs += e01 + e23;   // the sums as one partial per class parity, added up behind the class loop
+        if constexpr (TPOW > 1) z1 += pow_t<TPOW>(e01) + pow_t<TPOW>(e23);
+        ps = pk_fma(tp[c0 >> 1], v01, ps);   // sum_c p_c s_c
+        ps = pk_fma(tp[(c0 >> 1) + 1], v23, ps);
     }
 }
 
@@ -1353,7 +1347,7 @@ __global__ __launch_bounds__(THREADS, 4) void kdlite_head2_kernel(HeadArgs h) {
         const int r = px_first + tid;   // the lane's pixel inside the image
         const bool live = r < HW;
         // everything the lane needs from memory is requested first: its teacher probabilities, label, entropy term
-        float tp[CPAD];
+        f32x2_t tp[CPAD / 2];   // the teacher's probabilities, class pairs
         long long lab = -1;
         float hn = 0.f;
         if constexpr (LOSS) {
@@ -1366,11 +1360,13 @@ __global__ __launch_bounds__(THREADS, 4) void kdlite_head2_kernel(HeadArgs h) {
             const int rb = (live ? r : 0) * 4;
 #ifndef SPICE_HEAD2_TIMING_NO_TEACHER
 #pragma unroll
-            for (int c = 0; c < CPAD; ++c)
-                tp[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(planes, rb, c * HW * 4, 2 /* non-temporal */));
+            for (int c = 0; c < CPAD; c += 2) {
+                tp[c >> 1].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(planes, rb, c * HW * 4, 2 /* non-temporal */));
+                tp[c >> 1].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(planes, rb, (c + 1) * HW * 4, 2));
+            }
 #else
 #pragma unroll
-            for (int c = 0; c < CPAD; ++c) tp[c] = 0.01f * (float)c;
+            for (int c = 0; c < CPAD; c += 2) tp[c >> 1] = (f32x2_t)(0.01f * (float)c);
 #endif
             if (live) hn = __builtin_nontemporal_load(h.hneg + (long long)n * a.HW + r);
         }
@@ -1402,11 +1398,14 @@ __global__ __launch_bounds__(THREADS, 4) void kdlite_head2_kernel(HeadArgs h) {
         if constexpr (LOSS) {
             for (int j = tid; j < rows * WC; j += THREADS) {
                 const f32x4_t *p = reinterpret_cast<const f32x4_t *>(stage + j * CPAD);
+                // NaN-propagating maxima (v_maximum3_f32: no canonicalising moves); a NaN here sends the pixels around it
+                // to the exact walk
                 float m = kNegFill;
 #pragma unroll
                 for (int s4 = 0; s4 < CPAD / 4; ++s4) {
                     const f32x4_t x = p[s4];
-                    m = fmaxf(fmaxf(m, fmaxf(x.x, x.y)), fmaxf(x.z, x.w));
+                    m = __builtin_elementwise_maximum(__builtin_elementwise_maximum(m, x.x), x.y);
+                    m = __builtin_elementwise_maximum(__builtin_elementwise_maximum(m, x.z), x.w);
                 }
                 smax[j] = m;
             }
@@ -1435,13 +1434,18 @@ __global__ __launch_bounds__(THREADS, 4) void kdlite_head2_kernel(HeadArgs h) {
         const float *top = stage + jt * CPAD, *bot = stage + jb * CPAD;
         float best = -__builtin_inff();
         int arg = 0;
-        float zs = 0.f, z1 = 0.f, ps = 0.f, M = 0.f;
-        if constexpr (LOSS) M = fmaxf(fmaxf(smax[jt], smax[jt + 1]), fmaxf(smax[jb], smax[jb + 1]));
+        f32x2_t zs2 = (f32x2_t)(0.f), z12 = (f32x2_t)(0.f), ps2 = (f32x2_t)(0.f);
+        float M = 0.f;
+        if constexpr (LOSS)
+            M = __builtin_elementwise_maximum(__builtin_elementwise_maximum(smax[jt], smax[jt + 1]),
+                                              __builtin_elementwise_maximum(smax[jb], smax[jb + 1]));
+        const float mk = -M * k2;
 #pragma unroll
         for (int c0 = 0; c0 < CPAD; c0 += 4) {
             if (c0 >= C) break;   // wave-uniform
-            head2_step<CPAD, TPOW, LOSS>(top, bot, w0, w1, h0, h1, c0, best, arg, M, k2, zs, z1, ps, tp);
+            head2_step<CPAD, TPOW, LOSS>(top, bot, w0, w1, h0, h1, c0, best, arg, mk, k2, zs2, z12, ps2, tp);
         }
+        const float zs = zs2.x + zs2.y, z1 = z12.x + z12.y, ps = ps2.x + ps2.y;
         arg = arg >= C ? 0 : arg;   // a padding class wins only where every real logit is -infinity: class 0
         if (best != best) {
             // a NaN among the pixel's logits: the exact class-by-class walk (a NaN is the maximum, the first one wins)
@@ -1458,7 +1462,8 @@ __global__ __launch_bounds__(THREADS, 4) void kdlite_head2_kernel(HeadArgs h) {
         acc[0] += best + (float)arg + zs + z1 + ps;
         continue;
 #endif
-        const int id = (lab >= 0 && lab < C) ? (int)lab : ((LOSS && lab == a.ignore_index) ? -1 : -2);
+        // one unsigned comparison decides "a class"
+        const int id = ((unsigned long long)lab < (unsigned long long)C) ? (int)lab : ((LOSS && lab == a.ignore_index) ? -1 : -2);
         if (id >= 0) atomicAdd(&hist[id * C + arg], 1u);
         if constexpr (!LOSS) continue;
 
@@ -1493,13 +1498,67 @@ __global__ __launch_bounds__(THREADS, 4) void kdlite_head2_kernel(HeadArgs h) {
     }
     if (LOSS && bad) atomicAdd(reinterpret_cast<unsigned long long *>(a.bad), (unsigned long long)bad);
     __syncthreads();   // (a workgroup without a tile has not passed a barrier since it cleared the histogram)
-    conf_finish<THREADS>(lds_hist, h.copies, h.stride, C * C, 0u, h.tail);
-    if constexpr (!LOSS) return;
-    double out8[8];
+    if constexpr (!LOSS) {
+        conf_finish<THREADS>(lds_hist, h.copies, h.stride, C * C, 0u, h.tail);
+    } else {
+        // Both tails at once.  Separately (conf_finish, then kd_publish_and_finalize) they are two chains of dependent
+        // trips to memory, one behind the other: stores -> wait -> ticket -> last arriver's loads.  Here the workgroup
+        // stores its histogram row AND its four loss sums, waits once, and two lanes take the two tickets (the
+        // histogram's group ticket, the loss's grid-wide one) in the same trip.
+        const int bins = C * C;
+        {
+            const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) out8[k] = k < 4 ? acc[k % 4] : 0.0;
-    __syncthreads();
-    kd_publish_and_finalize<THREADS>(a, out8, red);
+            for (int k = 0; k < 4; ++k) {
+                const double v = wave_sum(acc[k]);
+                if (lane == 0) red[wave][k] = v;
+            }
+        }
+        unsigned *row = h.tail.partial + (int64_t)blockIdx.x * bins;
+        for (int b = tid; b < bins; b += THREADS) {
+            unsigned sum = 0;
+            for (int c = 0; c < h.copies; ++c) sum += lds_hist[c * h.stride + b];
+            __hip_atomic_store(row + b, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (tid < 8) {
+            double v = 0.0;
+            if (tid < 4)
+                for (int wv = 0; wv < THREADS / 64; ++wv) v += red[wv][tid];
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.main_partial) + (long long)blockIdx.x * 8 + tid,
+                               (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __shared__ int last_of_group, last_of_grid;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int g = blockIdx.x / h.tail.group;
+        const int first = g * h.tail.group;
+        const int members = min(h.tail.group, (int)gridDim.x - first);
+        if (tid == 0) {
+            const unsigned k = __hip_atomic_fetch_add(h.tail.tickets + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (k == (unsigned)(members - 1));
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(h.tail.tickets + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            last_of_group = last;
+        }
+        if (tid == 64) {   // another wave: its ticket travels beside the first
+            const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (t == gridDim.x - 1);
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            last_of_grid = last;
+        }
+        __syncthreads();
+        if (last_of_group) conf_fold_group<THREADS>(h.tail, first, members, bins);
+        if (last_of_grid) {
+            kd_finalize<THREADS>(a.main_partial, (int)gridDim.x, a.totals, a.out3, a.T, a.alpha, a.bw, a.conf);
+            if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 

@@ -45,6 +45,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--labels", type=str, default="uniform", choices=["uniform", "blocky"],
+                    help="label map of the head rows: uniform random, or 64x64 blocks (as real label maps, and as bench.py)")
     ap.add_argument("--imp-targets", type=str, default="")
     args = ap.parse_args()
     only = set(x for x in args.only.split(",") if x)
@@ -191,7 +193,7 @@ def main():
         # labels at 512x512; one launch against the three it replaces (up-sampling, arg-max histogram, loss)
         n, c, h, w = 8, 21, 512, 512
         _, t = synth.logits_pair(77, n, c, h, w)
-        lab = torch.from_numpy(synth.label_map(77, n, h, w, c)).to(dev)
+        lab = torch.from_numpy(synth.label_map(77, n, h, w, c, args.labels)).to(dev)
         teachers = [torch.from_numpy(t).to(dev) + k for k in range(3)]
         lows = [torch.randn(n, c, h // 4, w // 4, device=dev).half() for _ in range(3)]
         conf = torch.zeros(c, c, dtype=torch.int64, device=dev)

@@ -18,9 +18,11 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
+#include <hip/hip_runtime_api.h>
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
 #include <limits>
 #include <tuple>
 #include <vector>
@@ -164,8 +166,33 @@ void confusion_update_static(Tensor conf, const Tensor &preds, const Tensor &tar
         bad = invalid_count->data_ptr<int64_t>();
     }
     c10::DeviceGuard guard(conf.device());
+    void *stream = current_stream(conf);
+    {
+        // Calls on one GPU share that GPU's table and tickets, so they must not overlap.  A caller that moves from one
+        // stream to another gets the previous stream drained first (a host wait, on the change of stream only): a
+        // mistake costs time, not a wrong matrix.  Streams under graph capture cannot be waited for and are left to
+        // the caller, as the header says.
+        static std::mutex mu;
+        static void *last_stream[64];
+        static bool used[64];
+        const int d = conf.device().index();
+        if (d >= 0 && d < 64) {
+            std::lock_guard<std::mutex> lock(mu);
+            if (used[d] && last_stream[d] != stream) {
+                hipStreamCaptureStatus was = hipStreamCaptureStatusNone, now = hipStreamCaptureStatusNone;
+                const bool known = hipStreamIsCapturing(static_cast<hipStream_t>(last_stream[d]), &was) == hipSuccess &&
+                                   hipStreamIsCapturing(static_cast<hipStream_t>(stream), &now) == hipSuccess;
+                if (known && was == hipStreamCaptureStatusNone && now == hipStreamCaptureStatusNone)
+                    (void)hipStreamSynchronize(static_cast<hipStream_t>(last_stream[d]));
+                else
+                    (void)hipGetLastError();   // (a stream destroyed since: nothing of it can still be running)
+            }
+            used[d] = true;
+            last_stream[d] = stream;
+        }
+    }
     check_rc(spice_confusion_update_static(preds.data_ptr<int64_t>(), target.data_ptr<int64_t>(), preds.numel(),
-                                           (int32_t)num_classes, conf.data_ptr<int64_t>(), bad, current_stream(conf)),
+                                           (int32_t)num_classes, conf.data_ptr<int64_t>(), bad, stream),
              "spice_confusion_update_static");
 }
 

@@ -106,6 +106,15 @@ def _fp16_matrix(weight: torch.Tensor) -> torch.Tensor:
     return ent[2]
 
 
+def _within_kernel_offsets(cin: int, cout: int, taps: int, height: int, width: int, stride: int) -> bool:
+    """The limits of the library's matrix-core convolution beyond the layout ones: it addresses the weights and one
+    image of x with 32-bit byte offsets (both below 2^30 - 2^20 bytes) and takes at most 2^28 result pixels per image.
+    Past them its entry points decline (SPICE_ERR_UNSUPPORTED), so the predicates below must say "torch's conv2d"."""
+    limit = (1 << 30) - (1 << 20)
+    return (cout * taps * cin * 2 <= limit and cin * height * width * 2 <= limit
+            and (height // stride) * (width // stride) <= (1 << 28) and cin <= (1 << 16) and cout <= (1 << 20))
+
+
 class StemConv7x7(nn.Conv2d):
     """nn.Conv2d(in_ch, out_ch, 7, stride=2, padding=3, bias=False): the ResNet stem.  On fp16 activations (autocast)
     under no_grad on a HIP device, an even height and a width that is a multiple of 16, the forward is one launch of
@@ -121,6 +130,7 @@ class StemConv7x7(nn.Conv2d):
                 and self.kernel_size == (7, 7) and self.stride == (2, 2) and self.padding == (3, 3)
                 and self.dilation == (1, 1) and self.padding_mode == "zeros" and height % 2 == 0 and width % 16 == 0
                 and self.in_channels <= 1024
+                and _within_kernel_offsets(self.in_channels, self.out_channels, 49, height, width, 2)
                 and (x_dtype == torch.float16 or
                      (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16)))
 
@@ -155,7 +165,8 @@ class Conv1x1(nn.Conv2d):
         """Whether forward() on a plane of this size is a launch of the library (no MIOpen call, no solver lookup)."""
         if self.takes_matrix_path(x_dtype):
             return True
-        return self.stride == (2, 2) and self._plain_fp16(x_dtype) and height % 2 == 0 and width % 16 == 0
+        return (self.stride == (2, 2) and self._plain_fp16(x_dtype) and height % 2 == 0 and width % 16 == 0
+                and _within_kernel_offsets(self.in_channels, self.out_channels, 1, height, width, 2))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4:
@@ -265,7 +276,8 @@ def conv3x3_served_by_library(conv: nn.Conv2d, x_dtype: torch.dtype, height: int
             and conv.groups == 1 and conv._parameters["bias"] is None and conv.padding_mode == "zeros"
             and (x_dtype == torch.float16 or
                  (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16))
-            and height % s == 0 and width % s == 0 and (width // s) % 8 == 0 and width >= 8)
+            and height % s == 0 and width % s == 0 and (width // s) % 8 == 0 and width >= 8
+            and _within_kernel_offsets(conv.in_channels, conv.out_channels, 9, height, width, s))
 
 
 def conv3x3_bn(conv: nn.Conv2d, bn: BatchNormAct2d, x):

@@ -433,7 +433,16 @@ class SensitivitySweep:
                  kd_out: Optional[torch.Tensor] = None, first_lane: bool = False) -> int:
         """Enqueue one candidate; conf_out [C,C] int64 (+=), kd_out [3] fp32 (=).  Returns the
         algorithmic bytes of the gather launch.  first_lane: on this network and the current stream whatever lane
-        the candidate belongs to (measurements that want one candidate on the device at a time)."""
+        the candidate belongs to (measurements that want one candidate on the device at a time).
+
+        Ordering with lanes enabled (enable_lanes(k > 1)): a candidate of another lane is launched on that lane's
+        stream, which is ordered behind the current stream only at fork_lanes().  The caller queues `images`,
+        `labels`, `teacher_logits` and the cleared `conf_out` / `kd_out` on the current stream, calls fork_lanes(),
+        then evaluate() as often as it likes, and calls join_lanes() before it reads the outputs or frees / rewrites
+        the inputs on the current stream (run() and lane_context() do exactly this).  evaluate() does not order the
+        lane's stream behind the current one itself: that would put every lane behind the first lane's candidates
+        and undo the overlap the lanes exist for.  A new teacher tensor is the one exception: its prepared parts
+        are made on the current stream between a join and a fork of their own."""
         lane = self if first_lane else self._lane_of(index)
         tape = self._tape_for(images)
         replay = tape.replay(self.first_unit(index)) if tape is not None else None
@@ -458,6 +467,8 @@ class SensitivitySweep:
         # back from the allocator holding another teacher's logits
         key = (teacher_logits._version, float(self.kd["temperature"]))
         if self._teacher_src is not teacher_logits or self._teacher_key != key:
+            if self._teacher_prepared is not None:
+                self.join_lanes()   # head launches still queued on the lanes' streams read the parts released here
             self._teacher_src, self._teacher_key, self._teacher_prepared = teacher_logits, key, None
             if teacher_logits.is_cuda and teacher_logits.dtype == torch.float32 and teacher_logits.is_contiguous():
                 self._teacher_prepared = ops.kd_teacher_prepare(teacher_logits, self.kd["temperature"])

@@ -178,6 +178,37 @@ def test_sweep_head_declines_what_it_does_not_cover(dev):
         ops.sweep_head(low, t, lab[:, :5], conf, scale_factor=4.0, temperature=4.0, alpha=0.5)
 
 
+def test_head_entries_decline_stages_near_the_lds_limit(dev):
+    """Class counts and source widths whose LDS stage walks across the kernels' limits (the dynamic part plus the
+    kernels' own static arrays must fit the 64 KiB a launch may ask for): every shape is either served, with the
+    tables of the separate launches, or declined with SPICE_ERR_UNSUPPORTED (None here) - never a failed launch."""
+    kw = dict(temperature=4.0, alpha=0.7)
+    served = declined = 0
+    for c in (17, 21, 24, 29):
+        for in_w in range(8, 264, 8):
+            h, scale = 6, 2
+            low, teacher, lab = _inputs(c * 1000 + in_w, 1, c, h, in_w, scale)
+            low_d, t_d, lab_d = (torch.from_numpy(x).to(dev) for x in (low, teacher, lab))
+            ref_conf, ref_out3, _ = _three_launches(dev, low_d, t_d, lab_d, c, scale, False, kw)
+            parts = ops.kd_teacher_prepare(t_d, kw["temperature"])
+            for teacher_arg, extra in ((t_d, {}), (parts[0], {"teacher_hneg": parts[1]})):
+                conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
+                out3 = ops.sweep_head(low_d, teacher_arg, lab_d, conf, align_corners=False, scale_factor=float(scale),
+                                      **extra, **kw)
+                if out3 is None:
+                    declined += 1
+                    assert int(conf.sum()) == 0
+                    continue
+                served += 1
+                np.testing.assert_array_equal(conf.cpu().numpy(), ref_conf.cpu().numpy())
+                np.testing.assert_allclose(out3.cpu().numpy(), ref_out3.cpu().numpy(), rtol=REL, atol=0)
+            conf = torch.zeros(c, c, dtype=torch.int64, device=dev)
+            if ops.upsample_argmax_confusion(conf, low_d, lab_d, scale_factor=float(scale), align_corners=False):
+                np.testing.assert_array_equal(conf.cpu().numpy(), ref_conf.cpu().numpy())
+    torch.cuda.synchronize()
+    assert served > 0 and declined > 0
+
+
 def test_sweep_uses_the_head_launch_and_gives_the_same_tables(dev):
     """SensitivitySweep with the one-launch head against the same sweep on the three separate launches:
     identical confusion matrices, losses to 1e-6."""

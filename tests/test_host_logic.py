@@ -225,6 +225,23 @@ def test_baseline_eval_configuration_matches_reference():
         create_model_from_config(dict(e, architecture="PSPNet"))
 
 
+def test_library_predicates_mirror_the_kernels_size_limits():
+    """served_by_library / conv3x3_served_by_library say "torch's conv2d" for planes past the matrix-core kernel's
+    32-bit byte offsets (one image of x and the weights below 2^30 - 2^20 bytes), where the C entry points decline."""
+    from spice_amd.nets import layers
+    f16 = torch.float16
+    c3 = nn.Conv2d(64, 64, 3, padding=1, bias=False)
+    assert layers.conv3x3_served_by_library(c3, f16, 512, 512)
+    assert layers.conv3x3_served_by_library(c3, f16, 2048, 4088)        # 64 * 2048 * 4088 * 2 B just below the limit
+    assert not layers.conv3x3_served_by_library(c3, f16, 2048, 4096)    # ... and just past it
+    stem = layers.StemConv7x7(3, 64)
+    assert stem.served_by_library(f16, 1024, 2048) and not stem.served_by_library(f16, 16384, 16384)
+    down = layers.Conv1x1(256, 512, stride=2)
+    assert down.served_by_library(f16, 128, 128) and not down.served_by_library(f16, 2048, 1024)
+    assert not layers._within_kernel_offsets(1 << 17, 8, 9, 8, 8, 1)      # more input channels than the kernel indexes
+    assert not layers._within_kernel_offsets(4096, 1 << 16, 9, 8, 8, 1)   # a weight matrix past the offsets
+
+
 def test_fused_modules_keep_torch_semantics_and_channel_coupling():
     """The inference modules of the model zoo on their torch path (CPU): BatchNormAct2d == batch-norm, add,
     ReLU; Conv1x1 / DepthwiseConv3x3 == conv2d; BilinearUp == UpsamplingBilinear2d; and the dependency

@@ -79,3 +79,27 @@ def test_static_entry_point_limits_are_return_codes():
     assert L.spice_confusion_update_static(x.data_ptr(), x.data_ptr(), 0, 4, conf.data_ptr(), None, None) == 0
     torch.cuda.synchronize()
     assert int(conf.sum().item()) == 0
+
+
+def test_static_torch_op_from_two_streams_in_turn():
+    """torch.ops.spice.confusion_update_static called from two streams alternately: the calls share the GPU's one
+    table, and the operator drains the previous stream when the stream changes, so the matrices are right."""
+    from spice_amd import ops
+    dev = torch.device("cuda:0")
+    classes, n = 21, 1 << 20
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    confs = [torch.zeros(classes, classes, dtype=torch.int64, device=dev) for _ in streams]
+    wants = [np.zeros((classes, classes), dtype=np.int64) for _ in streams]
+    data = []
+    for k in range(6):
+        p, t = _labels(900 + k, n, classes)
+        p.clamp_(0, classes - 1)
+        data.append((p.to(dev), t.to(dev)))
+        oc.update_confusion(wants[k % 2], p.numpy(), t.numpy(), classes)
+    torch.cuda.synchronize()
+    for k, (pd, td) in enumerate(data):
+        with torch.cuda.stream(streams[k % 2]):
+            ops.spice_ops().confusion_update_static(confs[k % 2], pd, td, classes, None)
+    torch.cuda.synchronize()
+    for conf, want in zip(confs, wants):
+        np.testing.assert_array_equal(conf.cpu().numpy(), want)

@@ -61,6 +61,7 @@ struct MmArgs {
     int tiles_m, tiles_n;   // per image
     unsigned total_tiles;
     int relu;
+    int chunked;            // 3x3, stride 1: K steps run over the nine taps of 64 channels before they move to the next 64
 };
 
 // Workgroups are dealt to the eight XCDs round-robin; consecutive tiles (same pixels, next 128 channels) share
@@ -277,9 +278,17 @@ __global__ __launch_bounds__(mm_threads(STAGES), MT == 1 ? 4 : 2) void conv1x1_b
         auto &rb = rb_all[S];
         auto &rb_meta = rb_meta_all[S];
         [[maybe_unused]] auto &ra_hi = ra_hi_all[S];
+        // the columns of W this step takes: K as it lies, or (chunked) tap t % 9 of channels 64 (t / 9) ..
+        int kcol = k0;
+        if constexpr (XMODE == kX3x3) {
+            if (a.chunked) {
+                const int t = k0 / kMmBK, blk = t / 9;
+                kcol = (t - 9 * blk) * a.cin + blk * kMmBK;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
-            const int off = a_off[i] + 2 * k0;
+            const int off = a_off[i] + 2 * kcol;
             if constexpr (W_ODD) {
                 // odd K: every other row of W starts in the middle of a dword.  The range check of a buffer load is
                 // per dword as addressed, so a dword that starts on W's last half would be dropped with it: read
@@ -337,7 +346,24 @@ __global__ __launch_bounds__(mm_threads(STAGES), MT == 1 ? 4 : 2) void conv1x1_b
                         }
                     }
                 }
-                // the next call is for the K step after this one: rows 64 further on
+                // the next call is for the K step after this one: rows 64 further on - or (chunked) the same
+                // channels at the next tap, whose lines of x the compute unit's L1 still holds, and 64 channels on
+                // after the ninth
+                if (XMODE == kX3x3 && a.chunked) {
+                    ++x3_tap[i];
+                    if (x3_dx[i] == a.dil) {
+                        x3_dx[i] = -a.dil;
+                        x3_dy[i] += a.dil;
+                    } else {
+                        x3_dx[i] += a.dil;
+                    }
+                    if (x3_tap[i] == 9) {
+                        x3_tap[i] = 0;
+                        x3_dy[i] = -a.dil;
+                        b_off[i] += kMmBK * x_plane * 2;   // beyond the last channel: outside the buffer, zeros
+                    }
+                    continue;
+                }
                 x3_ci[i] += kMmBK;
                 b_off[i] += kMmBK * x_plane * 2;
                 while (x3_ci[i] >= a.cin) {
@@ -608,11 +634,270 @@ __global__ __launch_bounds__(mm_threads(STAGES), MT == 1 ? 4 : 2) void conv1x1_b
     }
 }
 
+// ---- 3x3, stride 1, second form: the patch of x under a tile staged ONCE per 64 input channels --------------------
+//
+// The form above stages the X tile of every K step from memory, so each pixel of x crosses the L2 -> compute unit
+// path nine times (once per tap), and the weights go through LDS although every wave reads rows of its own.  Here
+//   * a tile is whole output rows (NPX pixels = rows x width), and the patch of x under it - (rows + 2 dil) x
+//     (width + 2 dil) pixels, zeros where it leaves the image - is staged once per block of 64 input channels,
+//     PIXEL-major: patch[pixel][64 channels + 8] halfs (144-byte rows).  A tap's view of the patch is the same
+//     image moved by (dy * pitch + dx) whole rows, so the A operand of the product (32 pixels x 16 channels) is ONE
+//     aligned ds_read_b128 per lane for every tap - nine products out of one staging;
+//   * the weights do not touch LDS: a lane's B operand (its channel's row of W, 8 consecutive K) is a 16-byte buffer
+//     load straight into the registers the product reads, requested three taps ahead;
+//   * four waves per workgroup, (32 MT) channels x (32 NT) pixels each, two workgroups per compute unit.
+// W is [Cout][9][Cin] as for the form above; Cin a multiple of 64 (no block of input channels ends inside a K step:
+// the pruned layers of a sweep candidate, whose channel counts are arbitrary, stay with the form above).
+struct C3Args {
+    const _Float16 *x, *w;
+    _Float16 *y;
+    const float *mean, *var, *weight, *bias;   // null mean: the plain product
+    float eps;
+    int relu;
+    int M, cin, h, w_px, dil;
+    int rows;         // output rows per tile
+    int prow;         // pixels per patch row: width + 2 dil
+    int prows;        // patch rows: rows + 2 dil
+    int buf_halfs;    // halfs of one patch buffer (a multiple of 8)
+    int buffers;      // 2 when there is more than one block of input channels
+    int batches;      // pieces of a patch per lane and tap (1 or 2)
+    int tiles_m, tiles_y;
+    unsigned total_tiles;
+};
+
+constexpr int kC3Pitch = 72;   // halfs per patch pixel
+
+template <int WM, int WN, int MT, int NT, int P>   // P: pieces of the next patch a lane stages per tap (9 P cover a patch)
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_mfma_kernel(C3Args a) {
+    constexpr int BM = 32 * MT * WM, NPX = 32 * NT * WN, THREADS = 256, PCS = NPX / 8;
+    constexpr int ROWS = BM * PCS / THREADS, RSTEP = THREADS / PCS, CP = NPX + 8;
+    constexpr int XP = kC3Pitch;
+    static_assert(WM * WN == 4, "four waves");
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const unsigned tile = mm_tile_of_block(blockIdx.x, a.total_tiles);
+    const int mt = static_cast<int>(tile % static_cast<unsigned>(a.tiles_m));
+    const unsigned rest = tile / static_cast<unsigned>(a.tiles_m);
+    const int ty = static_cast<int>(rest % static_cast<unsigned>(a.tiles_y));
+    const size_t img = rest / static_cast<unsigned>(a.tiles_y);
+    const int m0 = mt * BM, y0 = ty * a.rows;
+    const int W = a.w_px, plane = a.h * W, G = W >> 3;
+
+    for (int i = tid * 8; i < a.buffers * a.buf_halfs; i += THREADS * 8) *reinterpret_cast<uint4 *>(lds + i) = make_uint4(0, 0, 0, 0);
+
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(a.w), 0, (a.M * 9 * a.cin * 2 + 3) & ~3, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16 *>(a.x + img * static_cast<size_t>(a.cin) * plane), 0, a.cin * plane * 2, 0x00020000);
+    auto as_uint4 = [](u32x4_t v) { return make_uint4(v.x, v.y, v.z, v.w); };
+
+    // Piece q of a patch: 8 consecutive pixels of one channel.  Eight neighbouring lanes take the same 8 pixels of 8
+    // consecutive channels (q & 7), then the pieces along the row, the channel octets, the patch rows: a wave's request
+    // is 8 channels x 128 contiguous bytes.  The eight lanes transpose their 8 x 8 halfs among themselves, after which
+    // a lane holds ONE pixel's 8 channels - a 16-byte row piece of the pixel-major patch, one ds_write_b128.
+    // off: byte offset in the image of x (outside: reads zeros); dst: where the lane's transposed piece goes (-1:
+    // nowhere; rows outside the image keep the zeros the patch was cleared to).
+    // (the width is a power of two of at most 32 pieces, so G divides 32: a lane's j-th piece keeps its place g in
+    // the row and moves on by 32 / G octet-rows)
+    const int px_of_lane = 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + (lane & 1);   // the pixel the transposition leaves with the lane
+    const int g_shift = __builtin_ctz(G);
+    const int pc_g = (tid >> 3) & (G - 1), pc_t1 = (tid >> 3) >> g_shift, pc_dt = 32 >> g_shift;
+    const int pc_off = ((tid & 7) * plane + (y0 - a.dil) * W + 8 * pc_g) * 2;
+    const int pc_dst = (8 * pc_g + px_of_lane + a.dil) * XP;
+    auto piece = [&](int j, int cc, bool wanted, int &off, int &dst) {
+        const int t1 = pc_t1 + j * pc_dt;
+        const int r = t1 >> 3, c8 = t1 & 7;
+        const bool in = wanted && r < a.prows && static_cast<unsigned>(y0 - a.dil + r) < static_cast<unsigned>(a.h);
+        off = in ? pc_off + ((cc * 8 + c8) * 8 * plane + r * W) * 2 : kMmOutside;   // channels beyond cin: outside the buffer, zeros
+        dst = in ? pc_dst + r * (a.prow * XP) + 8 * c8 : -1;
+    };
+    const unsigned sel16 = (lane & 1) ? 0x03020706u : 0x05040100u;
+    auto store_piece = [&](uint4 v, int dst, _Float16 *buf) {
+        unsigned d0 = v.x, d1 = v.y, d2 = v.z, d3 = v.w;
+        // lanes l, l ^ 1: 2 x 2 blocks of halfs
+        d0 = __builtin_amdgcn_perm(__builtin_amdgcn_mov_dpp(d0, 0xB1, 0xF, 0xF, true), d0, sel16);
+        d1 = __builtin_amdgcn_perm(__builtin_amdgcn_mov_dpp(d1, 0xB1, 0xF, 0xF, true), d1, sel16);
+        d2 = __builtin_amdgcn_perm(__builtin_amdgcn_mov_dpp(d2, 0xB1, 0xF, 0xF, true), d2, sel16);
+        d3 = __builtin_amdgcn_perm(__builtin_amdgcn_mov_dpp(d3, 0xB1, 0xF, 0xF, true), d3, sel16);
+        {   // lanes l, l ^ 2: 2 x 2 blocks of dwords
+            const bool hi = (lane & 2) != 0;
+            const unsigned r0 = __builtin_amdgcn_mov_dpp(hi ? d0 : d2, 0x4E, 0xF, 0xF, true);
+            const unsigned r1 = __builtin_amdgcn_mov_dpp(hi ? d1 : d3, 0x4E, 0xF, 0xF, true);
+            const unsigned n0 = hi ? r0 : d0, n1 = hi ? d2 : r0, n2 = hi ? r1 : d1, n3 = hi ? d3 : r1;
+            d0 = n0, d1 = n1, d2 = n2, d3 = n3;
+        }
+        {   // lanes l, l ^ 4: 2 x 2 blocks of dword pairs
+            const bool hi = (lane & 4) != 0;
+            // lane l ^ 4 of a row of 16: four lanes up for the lanes of banks 0 and 2, four lanes down for banks 1 and 3
+            const unsigned s0 = hi ? d0 : d2, s1 = hi ? d1 : d3;
+            unsigned r0 = __builtin_amdgcn_update_dpp(0u, s0, 0x104 /* row_shl:4 */, 0xF, 0x5, false);
+            r0 = __builtin_amdgcn_update_dpp(r0, s0, 0x114 /* row_shr:4 */, 0xF, 0xA, false);
+            unsigned r1 = __builtin_amdgcn_update_dpp(0u, s1, 0x104, 0xF, 0x5, false);
+            r1 = __builtin_amdgcn_update_dpp(r1, s1, 0x114, 0xF, 0xA, false);
+            const unsigned n0 = hi ? r0 : d0, n1 = hi ? r1 : d1, n2 = hi ? d2 : r0, n3 = hi ? d3 : r1;
+            d0 = n0, d1 = n1, d2 = n2, d3 = n3;
+        }
+        if (dst >= 0) *reinterpret_cast<uint4 *>(buf + dst) = make_uint4(d0, d1, d2, d3);
+    };
+
+    // the lane's rows of W: channel m0 + 32 MT wave_m + 32 mi + (lane & 31), K from 8 h on
+    const int wave_m = wave % WM, wave_n = wave / WM;
+    int w_row[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        const int m = m0 + 32 * (MT * wave_m + mi) + (lane & 31);
+        w_row[mi] = m < a.M ? (m * 9 * a.cin + 8 * h) * 2 : kMmOutside;
+    }
+    constexpr int RD = 3;   // taps of W in flight
+    uint4 fw[RD][4][MT];
+    auto load_w = [&](int cc, int tap, int S) {   // S: a constant once the tap loop is unrolled
+        const int k = (tap * a.cin + cc * 64) * 2;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+                fw[S][s][mi] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_row[mi] + k + 32 * s, 0, 0));
+    };
+
+    // the lane's pixels: block b = NT wave_n + t, pixel 32 b + (lane & 31) of the tile; its place in the patch at tap (0, 0)
+    int px_base[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int p = 32 * (NT * wave_n + t) + (lane & 31);
+        const int py = p / W, pxx = p - py * W;
+        px_base[t] = ((py + a.dil) * a.prow + pxx + a.dil) * XP + 8 * h;
+    }
+
+    float16_t acc[MT][NT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][t][r] = 0.0f;
+
+    const int n_chunks = (a.cin + 63) >> 6;
+    load_w(0, 0, 0);
+    load_w(0, 1, 1);
+    load_w(0, 2, 2);
+    __syncthreads();   // the cleared patches
+    {   // the first block's patch: every piece requested before the first is stored
+        uint4 v[9 * P];
+        int dst[9 * P];
+#pragma unroll
+        for (int i = 0; i < 9 * P; ++i) {
+            int off;
+            piece(i, 0, true, off, dst[i]);
+            v[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < 9 * P; ++i) store_piece(v[i], dst[i], lds);
+    }
+    __syncthreads();
+
+    // the next block's patch: 2 P pieces requested per tap in taps 0 .. 4, stored three taps later (taps 3 .. 7), so
+    // that nothing of it is still on its way when the block ends
+    constexpr int XD = 3, XB = 2 * P;
+    uint4 xs[XD + 1][XB];
+    int xs_dst[XD + 1][XB];
+    for (int cc = 0; cc < n_chunks; ++cc) {
+        _Float16 *cur = lds + (a.buffers == 2 ? (cc & 1) * a.buf_halfs : 0);
+        _Float16 *nxt = lds + (a.buffers == 2 ? ((cc + 1) & 1) * a.buf_halfs : 0);
+        const bool more = cc + 1 < n_chunks;
+        half8_t fx[2][NT];
+        {
+            const int toff0 = (-a.dil * a.prow - a.dil) * XP;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) fx[0][t] = *reinterpret_cast<const half8_t *>(cur + px_base[t] + toff0);
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // (no load behind a branch: beyond the last block and beyond the patch the requests lie outside the buffer)
+            if (tap < 5) {
+#pragma unroll
+                for (int i = 0; i < XB; ++i) {
+                    int off;
+                    piece(XB * tap + i, cc + 1, more && XB * tap + i < 9 * P, off, xs_dst[tap % (XD + 1)][i]);
+                    xs[tap % (XD + 1)][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
+                }
+            }
+            if (tap >= XD && tap < 5 + XD) {
+#pragma unroll
+                for (int i = 0; i < XB; ++i) store_piece(xs[(tap - XD) % (XD + 1)][i], xs_dst[(tap - XD) % (XD + 1)][i], nxt);
+            }
+            // the operands of sub-step s + 1 (of the next tap behind the fourth) are requested from LDS before the
+            // products of sub-step s are issued: a wave alone on its SIMD hides the reads behind its own products
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int nx = 4 * tap + s + 1;   // the sub-step after this one, counted through the block
+                if (nx < 36) {
+                    const int ntap = nx >> 2, ns = nx & 3;
+                    const int ntoff = ((ntap / 3 - 1) * a.dil * a.prow + (ntap % 3 - 1) * a.dil) * XP;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        fx[nx & 1][t] = *reinterpret_cast<const half8_t *>(cur + px_base[t] + ntoff + 16 * ns);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    const uint4 wv = fw[tap % RD][s][mi];
+                    const half8_t wh = __builtin_bit_cast(half8_t, wv);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fx[(4 * tap + s) & 1][t], wh, acc[mi][t], 0, 0, 0);
+                }
+            }
+            // W of three taps on, into the registers just read
+            if (tap + RD < 9) load_w(cc, tap + RD, tap % RD);
+            else load_w(cc + 1, tap + RD - 9, tap % RD);
+        }
+        __syncthreads();
+    }
+
+    // accumulators -> fp16 -> C image [channel][pixel] -> row-major 16-byte pieces -> batch-norm tail -> memory
+    _Float16 *Cs = lds;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        const int row = 32 * (MT * wave_m + mi) + (lane & 31);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                half4_t v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = static_cast<_Float16>(acc[mi][t][4 * rq + e]);
+                *reinterpret_cast<half4_t *>(Cs + row * CP + 32 * (NT * wave_n + t) + 8 * rq + 4 * h) = v;
+            }
+    }
+    __syncthreads();
+    const int e_pc = (tid % PCS) * 8, e_row = tid / PCS;
+    const int e_p = y0 * W + e_pc;   // the piece's first pixel in the image
+    if (e_p >= plane) return;        // rows of the last tile beyond the image (pieces are whole: width % 8 == 0)
+    const bool has_bn = a.mean != nullptr;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const int row = e_row + RSTEP * i;
+        const int m = m0 + row;
+        if (m >= a.M) break;
+        half8_t v = *reinterpret_cast<const half8_t *>(Cs + row * CP + e_pc);
+        if (has_bn) {
+            const BnChannel pch = bn_channel_of(a.mean, a.var, a.weight, a.bias, a.eps, m);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const half2_t o = bn_tail_pair<false, false>(half2_t{v[e], v[e + 1]}, half2_t{0, 0}, pch, pch, a.relu);
+                v[e] = o[0];
+                v[e + 1] = o[1];
+            }
+        }
+        *reinterpret_cast<half8_t *>(a.y + (img * a.M + m) * static_cast<size_t>(plane) + e_p) = v;
+    }
+}
+
 SPICE_ENV_KNOB(mm_stages_knob, "SPICE_CONV1X1_STAGES", 0)
 SPICE_ENV_KNOB(mm_mt_knob, "SPICE_CONV1X1_MT", 0)
 SPICE_ENV_KNOB(mm_m64_knob, "SPICE_CONV_M64", 1)
 SPICE_ENV_KNOB(mm_m64_min_k_knob, "SPICE_CONV_M64_MIN_K", 256)
 SPICE_ENV_KNOB(mm_w16_knob, "SPICE_CONV_W16", 1)
+SPICE_ENV_KNOB(mm_chunked_knob, "SPICE_CONV3X3_CHUNKED", 1)
 
 }  // namespace spice
 
@@ -748,6 +1033,7 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     a.tiles_n = static_cast<int>(tiles_n);
     a.total_tiles = static_cast<unsigned>(tiles_m_used * tiles_n * n);
     a.relu = relu ? 1 : 0;
+    a.chunked = (c3 && c3_stride == 1 && cin % kMmBK == 0 && mm_chunked_knob() != 0) ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (c7) {
         if (form == 5 && (kdim & 1)) mm_launch<5, 1, kX7x7S2, false, true>(a, st);
@@ -825,6 +1111,90 @@ extern "C" int spice_conv7x7_stride2_f16(const void *x, const void *weight, void
                           nullptr, 0.0f, 0, kStem7x7, 0, stream);
 }
 
+SPICE_ENV_KNOB(c3_halo_knob, "SPICE_CONV3X3_HALO", 1)        // 0 = the 3x3 convolutions stay with the first form
+SPICE_ENV_KNOB(c3_halo_form_knob, "SPICE_CONV3X3_HALO_FORM", 0)   // 2 | 3 = that tile shape wherever it applies (A/B measurements)
+
+template <int WM, int WN, int MT, int NT, int P>
+static void c3_launch_p(const spice::C3Args &a, size_t lds_bytes, hipStream_t st) {
+    using namespace spice;
+    const auto kernel = conv3x3_halo_mfma_kernel<WM, WN, MT, NT, P>;
+    if (lds_bytes > 64 * 1024)   // (the host bounds it at 150 KB)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipLaunchKernelGGL(kernel, dim3(a.total_tiles), dim3(256), lds_bytes, st, a);
+}
+
+template <int WM, int WN, int MT, int NT>
+static void c3_launch(const spice::C3Args &a, size_t lds_bytes, hipStream_t st) {
+    if (a.batches == 1) c3_launch_p<WM, WN, MT, NT, 1>(a, lds_bytes, st);
+    else c3_launch_p<WM, WN, MT, NT, 2>(a, lds_bytes, st);
+}
+
+// The second 3x3 form where it applies (stride 1, an even number of input channels, a width that divides the tile's
+// pixels, a patch the lanes can stage within nine taps and two of which fit the LDS); SPICE_ERR_UNSUPPORTED otherwise,
+// for the caller to take the first form.
+static int conv3x3_halo_launch(const void *x, const void *weight9, void *y, int64_t n, int64_t cin, int32_t h, int32_t w,
+                               int64_t cout, int32_t dilation, const float *mean, const float *var,
+                               const float *bn_weight, const float *bn_bias, float eps, int32_t relu, void *stream) {
+    using namespace spice;
+    if (c3_halo_knob() == 0) return SPICE_ERR_UNSUPPORTED;
+    if (n <= 0 || cin <= 0 || cout <= 0 || x == nullptr || weight9 == nullptr || y == nullptr) return SPICE_ERR_UNSUPPORTED;
+    if (mean != nullptr && (var == nullptr || bn_weight == nullptr || bn_bias == nullptr)) return SPICE_ERR_UNSUPPORTED;
+    if ((cin & 63) || (w & 7) || !aligned16(x) || !aligned16(y) || (reinterpret_cast<uintptr_t>(weight9) & 3u)) return SPICE_ERR_UNSUPPORTED;
+    const int64_t limit = (int64_t{1} << 30) - (int64_t{1} << 20);
+    if (cout * 9 * cin * 2 > limit || cin * (int64_t)h * w * 2 > limit || cin > (1 << 16) || cout > (1 << 20)) return SPICE_ERR_UNSUPPORTED;
+    // Tile shapes: 2 = 128 channels x 128 pixels (a wave 32 x 128), 3 = 64 x 128 (a wave 32 x 64; layers of at most 64
+    // channels).  Measured on MI355X against the first form, batch 8 (tools/conv3x3_bench.py, us): 512 -> 512 at
+    // 32 x 32, dilation 2: 53.8 against 62.1; 128 -> 128 at 64 x 64: 20.2 against 21.3; 256 -> 256 at 32 x 32: 27.0
+    // against 25.0; 64 -> 64 at 128 x 128: 38.7 against 30.8.  It is taken by itself where it wins clearly - K of
+    // 4608 and more - and anywhere it applies with SPICE_CONV3X3_HALO_FORM=2|3.
+    const int forced = (int)c3_halo_form_knob();
+    int form = 0;
+    if (forced == 2 || forced == 3) form = forced;
+    else if (cin >= 512 && cout > 64) form = 2;
+    if (form == 0 || 128 % w != 0) return SPICE_ERR_UNSUPPORTED;
+    const int bm = form == 3 ? 64 : 128;
+    const int npx = 128;
+    C3Args a;
+    a.x = static_cast<const _Float16 *>(x);
+    a.w = static_cast<const _Float16 *>(weight9);
+    a.y = static_cast<_Float16 *>(y);
+    a.mean = mean;
+    a.var = var;
+    a.weight = bn_weight;
+    a.bias = bn_bias;
+    a.eps = eps;
+    a.relu = relu ? 1 : 0;
+    a.M = (int)cout;
+    a.cin = (int)cin;
+    a.h = h;
+    a.w_px = w;
+    a.dil = dilation;
+    a.rows = npx / w;
+    a.prow = w + 2 * dilation;
+    a.prows = a.rows + 2 * dilation;
+    a.buf_halfs = (a.prows * a.prow * kC3Pitch + 7) & ~7;
+    const int64_t chunks = ceil_div(cin, 64);
+    a.buffers = chunks > 1 ? 2 : 1;
+    if ((w & (w - 1)) != 0 || w > 256) return SPICE_ERR_UNSUPPORTED;   // a power of two: the lanes' pieces step through the patch in whole rows
+    const int64_t pieces = (int64_t)64 * a.prows * (w / 8);
+    a.batches = (int)ceil_div(pieces, 9 * 256);   // pieces per lane and tap
+    if (a.batches > 2) return SPICE_ERR_UNSUPPORTED;
+    size_t lds_bytes = (size_t)a.buffers * a.buf_halfs * 2;
+    const size_t c_bytes = (size_t)bm * (npx + 8) * 2;
+    if (lds_bytes < c_bytes) lds_bytes = c_bytes;
+    if (lds_bytes > 150 * 1024) return SPICE_ERR_UNSUPPORTED;
+    a.tiles_m = (int)ceil_div(cout, bm);
+    a.tiles_y = (int)ceil_div(h, a.rows);
+    const int64_t total = (int64_t)a.tiles_m * a.tiles_y * n;
+    if (total > INT32_MAX) return SPICE_ERR_UNSUPPORTED;
+    a.total_tiles = (unsigned)total;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (form == 3) c3_launch<2, 2, 1, 2>(a, lds_bytes, st);
+    else c3_launch<4, 1, 1, 4>(a, lds_bytes, st);
+    SPICE_LAUNCH_CHECK();
+    return SPICE_OK;
+}
+
 extern "C" int spice_conv3x3_bn_act_f16(const void *x, const void *weight9, void *y, int64_t n, int64_t cin, int32_t h,
                                         int32_t w, int64_t cout, int32_t stride, int32_t dilation, const float *mean,
                                         const float *var, const float *bn_weight, const float *bn_bias, float eps,
@@ -834,6 +1204,10 @@ extern "C" int spice_conv3x3_bn_act_f16(const void *x, const void *weight9, void
     // whole stride cells; rows of the result that are whole 16-byte pieces; the in-row start of an edge load needs 8 columns
     if (h % stride != 0 || w % stride != 0 || ((w / stride) & 7) != 0 || w < 8) return SPICE_ERR_UNSUPPORTED;
     if (cin > (1 << 16)) return SPICE_ERR_UNSUPPORTED;
+    if (stride == 1) {
+        const int rc = conv3x3_halo_launch(x, weight9, y, n, cin, h, w, cout, dilation, mean, var, bn_weight, bn_bias, eps, relu, stream);
+        if (rc != SPICE_ERR_UNSUPPORTED) return rc;
+    }
     return conv1x1_launch(x, weight9, y, n, cin, static_cast<int64_t>(h / stride) * (w / stride), cout, mean, var, bn_weight,
                           bn_bias, eps, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, relu, 0, h, w, nullptr, nullptr,
                           nullptr, nullptr, 0.0f, 0, stride, dilation, stream);

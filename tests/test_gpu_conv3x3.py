@@ -42,7 +42,10 @@ CASES = [(2, 16, 8, 16, 24, 1, 1), (1, 64, 16, 16, 64, 1, 1), (1, 40, 8, 8, 130,
          # ... and 128-pixel tiles (deep K, many tiles), M tail
          (8, 32, 64, 64, 130, 1, 1),
          # one round of 128-pixel tiles: the sixteen-wave form; M tail, K tail, dilation
-         (8, 32, 64, 64, 128, 1, 1), (6, 40, 64, 64, 100, 1, 2)]
+         (8, 32, 64, 64, 128, 1, 1), (6, 40, 64, 64, 100, 1, 2),
+         # the patch form (x staged once per 64 input channels, nine taps out of it; taken from 512 input channels on):
+         # dilation 2 on 32 x 32; an M tail; rows that do not fill the last tile, dilation 3; one 128-pixel row per tile
+         (2, 512, 32, 32, 512, 1, 2), (1, 512, 16, 16, 200, 1, 1), (1, 576, 10, 64, 130, 1, 3), (1, 512, 5, 128, 96, 1, 1)]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -62,7 +65,7 @@ def test_conv3x3_exact_on_integer_data(dev, case, relu):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 32, 32, 64, 1, 1), (2, 128, 32, 64, 128, 2, 1), (1, 256, 32, 32, 512, 1, 2),
-                                  (8, 64, 128, 128, 64, 1, 1)])
+                                  (8, 64, 128, 128, 64, 1, 1), (2, 512, 32, 32, 512, 1, 2)])
 def test_conv3x3_on_random_data(dev, case):
     n, cin, h, w, cout, stride, dil = case
     g = torch.Generator().manual_seed(sum(case) + 3)
@@ -112,3 +115,37 @@ def test_conv3x3_limits_and_bottleneck(dev):
             handle.remove()
         assert a.shape == b.shape
         assert float((a.float() - b.float()).abs().max()) <= 2.0 ** -7 * float(b.float().abs().max())
+
+
+_FORCED = """
+import sys, torch
+sys.path.insert(0, %r)
+from spice_amd import ops
+dev = torch.device("cuda:0")
+for n, cin, h, w, cout, dil in ((2, 64, 16, 128, 64, 1), (1, 128, 8, 32, 40, 2), (2, 192, 12, 64, 70, 1), (1, 64, 4, 8, 16, 7)):
+    g = torch.Generator().manual_seed(n + cin + h + w + cout + dil)
+    x = torch.randint(-3, 4, (n, cin, h, w), generator=g).half()
+    wt = torch.randint(-2, 3, (cout, cin, 3, 3), generator=g).half()
+    exact = torch.nn.functional.conv2d(x.double(), wt.double(), None, 1, dil, dil).half().contiguous().to(dev)
+    bn = torch.nn.BatchNorm2d(cout).eval()
+    bn.running_mean.copy_(torch.randn(cout, generator=g)); bn.running_var.copy_(torch.rand(cout, generator=g) * 2 + 0.05)
+    bn = bn.to(dev)
+    with torch.no_grad():
+        got = ops.conv3x3_bn_act(x.to(dev), wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().to(dev), bn, True, 1, dil)
+        want = ops.bn_act(exact, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, relu=True)
+    assert torch.equal(got, want), (n, cin, h, w, cout, dil)
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("form", ["2", "3"])
+def test_conv3x3_patch_form_forced_on_small_layers(form):
+    """Both tile shapes of the patch form on layers it is not taken for by itself (SPICE_CONV3X3_HALO_FORM is read
+    once per process, hence a process of its own): exact on integer data."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SPICE_CONV3X3_HALO_FORM=form)
+    out = subprocess.run([sys.executable, "-c", _FORCED % root], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr

@@ -700,6 +700,8 @@ def main():
     sweep.prepare(warm_list)
     sweep.warm_shapes(images, warm_list)
 
+    host_s = [0.0]
+
     def timed_region(first_time):
         """K candidates, wall-clock, barrier and device synchronisation on both sides; the first time it holds ALL
         per-candidate work of its K candidates: launch plans and index upload, the solver lookups for their new
@@ -721,6 +723,7 @@ def main():
             with sweep.lane_context(todo[i]):
                 table[todo[i]].zero_()
             moved += sweep.evaluate(todo[i], images, labels, teacher, table[todo[i]], kd[todo[i]])
+        host_s[0] = time.perf_counter() - t0   # the host has queued everything; what is left is the device catching up
         sweep.join_lanes()
         sdist.all_reduce_sum_(table)
         sdist.all_reduce_sum_(kd)
@@ -749,6 +752,7 @@ def main():
         sweep.kd_events = []
         reused0 = sweep.units_reused
         elapsed, prep_s, moved = timed_region(True)
+        host_first = host_s[0]
         units_reused = (sweep.units_reused - reused0) / max(args.steps, 1)
         kd_events = sweep.kd_events
         sweep.kd_events = None
@@ -760,6 +764,7 @@ def main():
         sweep.prefix_reuse = not sweep.prefix_reuse
         same_tables = bool(torch.equal(table_a, table[timed]))
         elapsed_again, _, _ = timed_region(False)   # and the timed form again without its plans: like for like
+        host_again = host_s[0]
     n_warm = len(sweep._warmed)
     kd_events_alone = kd_events
     if lanes > 1:
@@ -849,7 +854,12 @@ def main():
                                          "candidates_in_flight": lanes,
                                          "note": "the kernel's launches overlap the other lane's convolutions and share "
                                                  "the memory system with them"}},
-        "setup": {"miopen_find_db_warmup_s": round(tune_s, 1), "timed_prepare_s": round(prep_s, 4), "warm_mode": args.warm_mode,
+        "setup": {"miopen_find_db_warmup_s": round(tune_s, 1), "timed_prepare_s": round(prep_s, 4),
+                  "host_queued_everything_after_ms_per_step": {"timed_region": round(1e3 * host_first / args.steps, 3),
+                                                               "same_candidates_again": round(1e3 * host_again / args.steps, 3),
+                                                               "note": "wall time until the host has launched the region's last "
+                                                                       "kernel, per candidate; close to ms_per_step = the host, "
+                                                                       "not the device, sets the pace"}, "warm_mode": args.warm_mode,
                   "new_conv_problems_seen": n_warm, "taylor_calibration_s": round(taylor_s, 3), "taylor_batches": 2,
                   "lanes": lanes, "lanes_setup_s": round(lanes_s, 3),
                   "quota_layers": len(quotas), "gather_MB_per_candidate": round(moved / max(args.steps, 1) / 1e6, 2)},

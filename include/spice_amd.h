@@ -167,6 +167,22 @@ int spice_kdlite_forward(const float *student, const float *teacher, const int64
                          float coef_ce, float coef_kd, const float *upstream,
                          void *workspace, size_t workspace_bytes, void *stream);
 
+/* The label pass of spice_kdlite_forward's gradient form by itself: the loss normalisers (number of pixels that
+ * are not ignored, sum of the class weights of the labelled ones) depend on the labels alone, so a training step can
+ * take them on another stream while the student's and teacher's forwards run (pruning/trainer.py:172-183 computes the
+ * loss behind both forwards; the mean reductions of pruning/losses.py:39-55,144-160 are what the pass serves).  It
+ * writes them into `workspace`; spice_kdlite_forward_prepared is spice_kdlite_forward (same arguments, same results bit
+ * for bit) without that launch, on the same workspace, ordered behind the pass by the caller.  Both return
+ * SPICE_ERR_UNSUPPORTED for the boundary / confidence options (their pass reads the teacher's logits) and the prepared
+ * form for grad == NULL (the forward-only form has no separate pass): call spice_kdlite_forward then. */
+int spice_kdlite_label_pass(const int64_t *labels, int64_t n, int64_t c, int64_t h, int64_t w,
+                            const spice_kdlite_params *params, void *workspace, size_t workspace_bytes, void *stream);
+int spice_kdlite_forward_prepared(const float *student, const float *teacher, const int64_t *labels,
+                                  int64_t n, int64_t c, int64_t h, int64_t w,
+                                  const spice_kdlite_params *params, float *out3, float *grad,
+                                  float coef_ce, float coef_kd, const float *upstream,
+                                  void *workspace, size_t workspace_bytes, void *stream);
+
 /* Once per teacher of a sensitivity sweep: probs [N,C,H,W] fp32 = softmax(teacher / temperature) over C
  * and hneg [N,H,W] fp32 = sum_c probs ln probs, the teacher-only parts of PixelKDLoss
  * (pruning/losses.py:40-58), for spice_sweep_head_f16.  SPICE_ERR_UNSUPPORTED when H*W % 4 != 0 or a

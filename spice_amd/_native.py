@@ -81,6 +81,11 @@ SIGNATURES = {
     "spice_kdlite_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                        c_int64, POINTER(KdliteParams), c_void_p, c_void_p, c_float,
                                        c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "spice_kdlite_forward_prepared": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                                c_int64, POINTER(KdliteParams), c_void_p, c_void_p, c_float,
+                                                c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "spice_kdlite_label_pass": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_int64, POINTER(KdliteParams), c_void_p,
+                                          c_size_t, c_void_p]),
     "spice_kd_teacher_prepare": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p, c_void_p,
                                            c_void_p]),
     "spice_sweep_head_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,

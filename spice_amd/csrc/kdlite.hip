@@ -55,6 +55,7 @@ struct KdArgs {
     long long ignore_index;
     float invT, T, alpha, bw, coef_ce, coef_kd;
     int conf;
+    int pre_ready;   // host side only: the label pass has run into this workspace already (spice_kdlite_label_pass)
 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -335,7 +336,8 @@ static void kd_launch_prepass(KdArgs &a, bool ext, hipStream_t st) {
     long long g = (a.N * a.HW + (long long)kKdThreads * 16 - 1) / ((long long)kKdThreads * 16);
     if (g < 1) g = 1;
     if (g > kKdCountMaxBlocks) g = kKdCountMaxBlocks;
-    a.pre_blocks = (int)g;
+    a.pre_blocks = (int)g;   // a function of the label count alone: the same whoever launches the pass
+    if (a.pre_ready) return;
     hipLaunchKernelGGL(kdlite_label_count_kernel, dim3((unsigned)g), dim3(kKdThreads), 0, st, a);
 }
 
@@ -1662,11 +1664,11 @@ extern "C" size_t spice_kdlite_workspace_bytes(int64_t, int64_t, int64_t, int64_
     return kKdWorkspace;
 }
 
-extern "C" int spice_kdlite_forward(const float *student, const float *teacher, const int64_t *labels,
-                                    int64_t n, int64_t c, int64_t h, int64_t w,
-                                    const spice_kdlite_params *params, float *out3, float *grad,
-                                    float coef_ce, float coef_kd, const float *upstream,
-                                    void *workspace, size_t workspace_bytes, void *stream) {
+static int kdlite_forward_impl(const float *student, const float *teacher, const int64_t *labels,
+                               int64_t n, int64_t c, int64_t h, int64_t w,
+                               const spice_kdlite_params *params, float *out3, float *grad,
+                               float coef_ce, float coef_kd, const float *upstream,
+                               void *workspace, size_t workspace_bytes, void *stream, bool pre_ready) {
     if (!params || !out3 || !workspace) return SPICE_ERR_ARG;
     if (n < 0 || c < 1 || h < 0 || w < 0) return SPICE_ERR_ARG;
     if (c > INT32_MAX || h > INT32_MAX || w > INT32_MAX) return SPICE_ERR_UNSUPPORTED;
@@ -1683,6 +1685,7 @@ extern "C" int spice_kdlite_forward(const float *student, const float *teacher, 
     char *ws = static_cast<char *>(workspace);
 
     const bool ext = params->boundary_weight > 1.0f || params->confidence_weight != 0;
+    if (pre_ready && (ext || grad == nullptr)) return SPICE_ERR_UNSUPPORTED;   // (those forms have no separate label pass)
     const bool vec4 = (hw % 4 == 0) && aligned16(student) && aligned16(teacher) && aligned16(labels) &&
                       (grad == nullptr || aligned16(grad));
     const int vec = vec4 ? 4 : 1;
@@ -1720,6 +1723,7 @@ extern "C" int spice_kdlite_forward(const float *student, const float *teacher, 
     a.coef_ce = coef_ce;
     a.coef_kd = coef_kd;
     a.conf = params->confidence_weight != 0;
+    a.pre_ready = pre_ready ? 1 : 0;
 
     if (grad != nullptr && vec4 && c <= 8 && kd_regs_mode() != 0) return kd_launch_regs(a, ext, (int)blocks, st);
     const size_t stage_bytes = (size_t)c * 2 * kKdThreads * sizeof(float);
@@ -1744,6 +1748,49 @@ extern "C" int spice_kdlite_forward(const float *student, const float *teacher, 
     }
     return vec4 ? kd_launch<4>(a, grad != nullptr, ext, (int)blocks, st)
                 : kd_launch<1>(a, grad != nullptr, ext, (int)blocks, st);
+}
+
+extern "C" int spice_kdlite_forward(const float *student, const float *teacher, const int64_t *labels,
+                                    int64_t n, int64_t c, int64_t h, int64_t w,
+                                    const spice_kdlite_params *params, float *out3, float *grad,
+                                    float coef_ce, float coef_kd, const float *upstream,
+                                    void *workspace, size_t workspace_bytes, void *stream) {
+    return kdlite_forward_impl(student, teacher, labels, n, c, h, w, params, out3, grad, coef_ce, coef_kd, upstream,
+                               workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int spice_kdlite_forward_prepared(const float *student, const float *teacher, const int64_t *labels,
+                                             int64_t n, int64_t c, int64_t h, int64_t w,
+                                             const spice_kdlite_params *params, float *out3, float *grad,
+                                             float coef_ce, float coef_kd, const float *upstream,
+                                             void *workspace, size_t workspace_bytes, void *stream) {
+    return kdlite_forward_impl(student, teacher, labels, n, c, h, w, params, out3, grad, coef_ce, coef_kd, upstream,
+                               workspace, workspace_bytes, stream, true);
+}
+
+extern "C" int spice_kdlite_label_pass(const int64_t *labels, int64_t n, int64_t c, int64_t h, int64_t w,
+                                       const spice_kdlite_params *params, void *workspace, size_t workspace_bytes,
+                                       void *stream) {
+    if (!params || !workspace) return SPICE_ERR_ARG;
+    if (n < 0 || c < 1 || h < 0 || w < 0) return SPICE_ERR_ARG;
+    if (c > INT32_MAX || h > INT32_MAX || w > INT32_MAX) return SPICE_ERR_UNSUPPORTED;
+    if (workspace_bytes < kKdWorkspace) return SPICE_ERR_WORKSPACE;
+    if (!aligned16(workspace) || !aligned8(labels)) return SPICE_ERR_ARG;
+    if (params->boundary_weight > 1.0f || params->confidence_weight != 0) return SPICE_ERR_UNSUPPORTED;   // their pass reads the teacher
+    const int64_t hw = h * w;
+    if (n * hw > 0 && !labels) return SPICE_ERR_ARG;
+    if (hw > INT32_MAX - 4096) return SPICE_ERR_UNSUPPORTED;
+    KdArgs a = KdArgs{};
+    a.labels = reinterpret_cast<const long long *>(labels);
+    a.class_w = params->class_weight;
+    a.pre_partial = reinterpret_cast<double *>(static_cast<char *>(workspace) + kKdOffPre);
+    a.N = n;
+    a.HW = hw;
+    a.C = (int)c;
+    a.ignore_index = params->ignore_index;
+    kd_launch_prepass<1>(a, false, static_cast<hipStream_t>(stream));
+    SPICE_LAUNCH_CHECK();
+    return SPICE_OK;
 }
 
 SPICE_ENV_KNOB(knob_head_blocks_per_cu, "SPICE_HEAD_BLOCKS_PER_CU", 0)   // tuning knobs (host side only)

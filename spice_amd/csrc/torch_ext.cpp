@@ -233,7 +233,8 @@ std::tuple<Tensor, Tensor> kdlite_forward(const Tensor &student, const Tensor &t
                                           double temperature, double alpha, int64_t ignore_index,
                                           double boundary_weight, bool confidence_weight,
                                           const c10::optional<Tensor> &class_weight, bool want_grad, double coef_ce,
-                                          double coef_kd, const c10::optional<Tensor> &upstream, Tensor workspace) {
+                                          double coef_kd, const c10::optional<Tensor> &upstream, Tensor workspace,
+                                          bool normalisers_ready) {
     check_dev(student, "student_logits", at::kFloat);
     check_dev(teacher, "teacher_logits", at::kFloat);
     check_dev(labels, "labels", at::kLong);
@@ -269,12 +270,42 @@ std::tuple<Tensor, Tensor> kdlite_forward(const Tensor &student, const Tensor &t
     c10::DeviceGuard guard(student.device());
     Tensor out3 = at::empty({3}, student.options());
     Tensor grad = want_grad ? at::empty_like(student) : at::empty({0}, student.options());
-    check_rc(spice_kdlite_forward(student.data_ptr<float>(), teacher.data_ptr<float>(), labels.data_ptr<int64_t>(), n, c,
-                                  h, w, &p, out3.data_ptr<float>(), want_grad ? grad.data_ptr<float>() : nullptr,
-                                  (float)coef_ce, (float)coef_kd, up, workspace.data_ptr(), (size_t)workspace.numel(),
-                                  current_stream(student)),
-             "spice_kdlite_forward");
+    const auto entry = normalisers_ready ? spice_kdlite_forward_prepared : spice_kdlite_forward;
+    check_rc(entry(student.data_ptr<float>(), teacher.data_ptr<float>(), labels.data_ptr<int64_t>(), n, c, h, w, &p,
+                   out3.data_ptr<float>(), want_grad ? grad.data_ptr<float>() : nullptr, (float)coef_ce, (float)coef_kd, up,
+                   workspace.data_ptr(), (size_t)workspace.numel(), current_stream(student)),
+             normalisers_ready ? "spice_kdlite_forward_prepared" : "spice_kdlite_forward");
     return std::make_tuple(out3, grad);
+}
+
+// The loss normalisers of the gradient form from the labels alone, into `workspace` (for kdlite_forward(...,
+// normalisers_ready = true) on the same workspace).  False when the options have no separate label pass.
+bool kdlite_label_pass(const Tensor &labels, int64_t num_classes, int64_t ignore_index, double boundary_weight,
+                       bool confidence_weight, const c10::optional<Tensor> &class_weight, Tensor workspace) {
+    check_dev(labels, "labels", at::kLong);
+    check_dev(workspace, "workspace", at::kByte);
+    check_same_device(labels, workspace, "workspace");
+    TORCH_CHECK_VALUE(labels.dim() == 3, "labels must be [N,H,W], got ", labels.sizes());
+    spice_kdlite_params p;
+    p.temperature = 1.0f;
+    p.alpha = 0.5f;
+    p.boundary_weight = (float)boundary_weight;
+    p.confidence_weight = confidence_weight ? 1 : 0;
+    p.ignore_index = ignore_index;
+    p.class_weight = nullptr;
+    if (class_weight.has_value()) {
+        check_dev(*class_weight, "class_weight", at::kFloat);
+        check_same_device(labels, *class_weight, "class_weight");
+        TORCH_CHECK_VALUE(class_weight->numel() == num_classes, "class_weight must have C elements");
+        p.class_weight = class_weight->data_ptr<float>();
+    }
+    c10::DeviceGuard guard(labels.device());
+    const int rc = spice_kdlite_label_pass(labels.data_ptr<int64_t>(), labels.size(0), num_classes, labels.size(1),
+                                           labels.size(2), &p, workspace.data_ptr(), (size_t)workspace.numel(),
+                                           current_stream(labels));
+    if (rc == SPICE_ERR_UNSUPPORTED) return false;
+    check_rc(rc, "spice_kdlite_label_pass");
+    return true;
 }
 
 // Up-sampling + loss + arg-max histogram of a sweep candidate in one launch.  Returns out3, or a tensor
@@ -776,7 +807,9 @@ TORCH_LIBRARY(spice, m) {
           "Tensor(b!) workspace) -> ()", &argmax_confusion_update);
     m.def("kdlite_forward(Tensor student, Tensor teacher, Tensor labels, float temperature, float alpha, "
           "int ignore_index, float boundary_weight, bool confidence_weight, Tensor? class_weight, bool want_grad, "
-          "float coef_ce, float coef_kd, Tensor? upstream, Tensor(a!) workspace) -> (Tensor, Tensor)", &kdlite_forward);
+          "float coef_ce, float coef_kd, Tensor? upstream, Tensor(a!) workspace, bool normalisers_ready) -> (Tensor, Tensor)", &kdlite_forward);
+    m.def("kdlite_label_pass(Tensor labels, int num_classes, int ignore_index, float boundary_weight, bool confidence_weight, "
+          "Tensor? class_weight, Tensor(a!) workspace) -> bool", &kdlite_label_pass);
     m.def("scale_inplace(Tensor(a!) x, Tensor scale) -> ()", &scale_inplace);
     m.def("upsample_bilinear(Tensor x, int out_h, int out_w, bool align_corners, float scale_h, float scale_w, "
           "int out_dtype, Tensor(a!)? out) -> Tensor(a!)", &upsample_bilinear);

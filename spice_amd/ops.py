@@ -263,13 +263,16 @@ def kdlite_forward(student: torch.Tensor, teacher: torch.Tensor, labels: torch.T
                    boundary_weight: float = 1.0, confidence_weight: bool = False,
                    class_weight: Optional[torch.Tensor] = None, want_grad: bool = False,
                    coef: Optional[Tuple[float, float]] = None,
-                   upstream: Optional[torch.Tensor] = None
+                   upstream: Optional[torch.Tensor] = None,
+                   workspace: Optional[torch.Tensor] = None, normalisers_ready: bool = False
                    ) -> Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]:
     """Fused KD-Lite loss.  Returns (out3 = [total, ce, kd], grad or None, sums[8] fp64).
 
     grad = coef[0]*d(ce)/d(student) + coef[1]*d(kd)/d(student); coef defaults to
     (alpha, 1-alpha), i.e. d(total)/d(student).  `upstream` (device, 3 floats: incoming
     gradients of total/ce/kd) overrides coef on the device.
+    `workspace` + `normalisers_ready`: kdlite_label_pass has put the loss normalisers of these labels into this
+    workspace already (gradient form only); the call is ordered behind that pass by the caller.
     """
     if not student.is_cuda:
         nat.require_device_tensor(student, "student_logits", torch.float32)
@@ -277,15 +280,33 @@ def kdlite_forward(student: torch.Tensor, teacher: torch.Tensor, labels: torch.T
         raise ValueError("student/teacher logits must both be [N,C,H,W]")
     n, c, h, w = student.shape
     dev = student.device
-    ws = _workspace("kdlite", dev, nat.lib().spice_kdlite_workspace_bytes(n, c, h, w))
+    ws = workspace if workspace is not None else _workspace("kdlite", dev, nat.lib().spice_kdlite_workspace_bytes(n, c, h, w))
     cce, ckd = coef if coef is not None else (float(alpha), 1.0 - float(alpha))
     out3, grad = spice_ops().kdlite_forward(student, teacher, labels, float(temperature), float(alpha),
                                             int(ignore_index), float(boundary_weight), bool(confidence_weight),
-                                            class_weight, bool(want_grad), cce, ckd, upstream, ws)
+                                            class_weight, bool(want_grad), cce, ckd, upstream, ws,
+                                            bool(normalisers_ready and want_grad))
     if not want_grad:
         grad = None
     sums = ws[16:80].view(torch.float64)
     return out3, grad, sums
+
+
+def kdlite_workspace(device: torch.device) -> torch.Tensor:
+    """A zeroed workspace of a caller's own for kdlite_label_pass / kdlite_forward(workspace=...)."""
+    return torch.zeros(nat.lib().spice_kdlite_workspace_bytes(1, 1, 1, 1), dtype=torch.uint8, device=device)
+
+
+def kdlite_label_pass(labels: torch.Tensor, num_classes: int, workspace: torch.Tensor, *, ignore_index: int = 255,
+                      boundary_weight: float = 1.0, confidence_weight: bool = False,
+                      class_weight: Optional[torch.Tensor] = None) -> bool:
+    """The label pass of the loss's gradient form by itself, on the current stream, into `workspace`: what the loss
+    divides by depends on the labels alone, so a training step can take it beside the networks' forwards.  False when
+    the options have no separate label pass (boundary / confidence weighting): nothing was launched."""
+    if not labels.is_cuda:
+        nat.require_device_tensor(labels, "labels", torch.int64)
+    return bool(spice_ops().kdlite_label_pass(labels, int(num_classes), int(ignore_index), float(boundary_weight),
+                                              bool(confidence_weight), class_weight, workspace))
 
 
 def upsample_argmax_confusion(conf: torch.Tensor, low: torch.Tensor, target: torch.Tensor, *,

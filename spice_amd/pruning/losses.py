@@ -24,7 +24,8 @@ class _KDLiteFunction(torch.autograd.Function):
         # autograd runs forward() with grad mode switched off, and needs_input_grad ignores torch.no_grad()
         ctx.set_materialize_grads(False)
         out3, grad, _ = ops.kdlite_forward(student.detach(), teacher.detach(), labels, want_grad=want, **opts)
-        ctx.opts = opts
+        # (a recomputation in backward takes the label pass again: the prepared normalisers belong to this launch)
+        ctx.opts = {k: v for k, v in opts.items() if k not in ("workspace", "normalisers_ready")}
         ctx.saved_grad = grad
         ctx.save_for_backward(student, teacher, labels)
         return out3[0], out3[1], out3[2]
@@ -79,12 +80,42 @@ class KDLiteLoss(nn.Module):
         self.num_classes = num_classes
         self.ce_loss = SegmentationLoss(num_classes, ignore_index)
         self.kd_loss = PixelKDLoss(temperature)
+        self._side = self._ws = self._prepared = None
+
+    def prepare_labels(self, labels: torch.Tensor) -> bool:
+        """Optional, before the networks' forwards of a training step: what the loss divides by (the pixels that are
+        not ignored, the class weights of the labelled ones) depends on the labels alone, so the loss kernel's label
+        pass is launched now, on a stream of its own, and the next forward() on the same labels tensor finds the
+        result ready instead of launching the pass in front of its main kernel.  False (nothing done) for host
+        tensors, other dtypes and the boundary / confidence options, whose pass reads the teacher's logits."""
+        self._prepared = None
+        if (not labels.is_cuda or labels.dtype != torch.int64 or not labels.is_contiguous() or labels.dim() != 3
+                or self.boundary_weight > 1.0 or self.confidence_weight):
+            return False
+        dev = labels.device
+        if self._side is None or self._ws.device != dev:
+            self._side, self._ws = torch.cuda.Stream(device=dev), ops.kdlite_workspace(dev)
+        # behind what produced the labels, and behind the last loss launch that read this workspace
+        self._side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self._side):
+            done = ops.kdlite_label_pass(labels, self.num_classes, self._ws, ignore_index=self.ignore_index,
+                                         class_weight=self.ce_loss.class_weights)
+            ready = torch.cuda.Event()
+            ready.record()
+        if done:
+            self._prepared = (labels, labels._version, ready)
+        return done
 
     def forward(self, student_logits: torch.Tensor, teacher_logits: torch.Tensor,
                 labels: torch.Tensor) -> Dict[str, torch.Tensor]:
         opts = dict(temperature=self.temperature, alpha=self.alpha, ignore_index=self.ignore_index,
                     boundary_weight=self.boundary_weight, confidence_weight=self.confidence_weight,
                     class_weight=self.ce_loss.class_weights)
+        prepared, self._prepared = self._prepared, None
+        if (prepared is not None and prepared[0] is labels and prepared[1] == labels._version
+                and student_logits.shape[1] == self.num_classes and torch.is_grad_enabled() and student_logits.requires_grad):
+            torch.cuda.current_stream(labels.device).wait_event(prepared[2])
+            opts.update(workspace=self._ws, normalisers_ready=True)
         total, ce, kd = _apply(_prepare(student_logits), _prepare(teacher_logits), labels.long().contiguous(), opts)
         return {"total": total, "ce": ce, "kd": kd}
 

@@ -142,6 +142,10 @@ class PruningTrainer:
             images, masks = images.to(dev), masks.to(dev)
             self._zero_grad(optimizer)
             if kd_active:
+                # the loss's label pass beside the two forwards, on a stream of its own (the loss is computed
+                # behind both: pruning/trainer.py:172-183)
+                if hasattr(self.kd_loss_fn, "prepare_labels"):
+                    self.kd_loss_fn.prepare_labels(masks)
                 student_out = model(images)
                 with torch.no_grad():
                     teacher_out = self.distiller.teacher_model(images)

@@ -59,6 +59,51 @@ def test_kdlite_module_forward_backward(dev, name):
     assert t.grad is None
 
 
+@pytest.mark.parametrize("name", ["c21_default", "c5_weighted", "c19_odd_hw"])
+def test_kdlite_label_pass_beside_the_forwards(dev, name):
+    """KDLiteLoss.prepare_labels: the loss's label pass on a stream of its own before the networks' forwards
+    (pruning/trainer.py:172-183 computes the loss behind both); the loss launch then skips the pass.  Same kernels on
+    the same values: loss and gradient are those of the plain call bit for bit, and the reference's within 1e-5."""
+    from spice_amd import ops
+    T, alpha, bw, conf, c = KD[f"{name}/params"]
+    t = torch.from_numpy(KD[f"{name}/teacher"]).to(dev)
+    lab = torch.from_numpy(KD[f"{name}/labels"]).to(dev)
+    plain = KDLiteLoss(temperature=float(T), alpha=float(alpha), num_classes=int(c)).to(dev)
+    s0 = torch.from_numpy(KD[f"{name}/student"]).to(dev).requires_grad_(True)
+    want = plain(s0, t, lab)
+    want["total"].backward()
+    loss = KDLiteLoss(temperature=float(T), alpha=float(alpha), num_classes=int(c)).to(dev)
+    calls = []
+    real = ops.kdlite_forward
+    try:
+        ops.kdlite_forward = lambda *a, **k: (calls.append(bool(k.get("normalisers_ready"))), real(*a, **k))[1]
+        for step in range(2):   # the second step finds the workspace the first one used
+            s = torch.from_numpy(KD[f"{name}/student"]).to(dev).requires_grad_(True)
+            assert loss.prepare_labels(lab)
+            _ = (s * 2).sum()   # (the forwards of a step go here)
+            got = loss(s, t, lab)
+            got["total"].backward()
+            for k in ("total", "ce", "kd"):
+                assert got[k].item() == want[k].item()
+            assert torch.equal(s.grad, s0.grad)
+        assert calls == [True, True]
+        # labels that were not prepared, and a forward without gradient: the plain call
+        calls.clear()
+        loss.prepare_labels(lab)
+        got = loss(s0.detach().requires_grad_(True), t, lab.clone())
+        with torch.no_grad():
+            loss.prepare_labels(lab)
+            loss(s0, t, lab)
+        assert calls == [False, False] and got["total"].item() == want["total"].item()
+    finally:
+        ops.kdlite_forward = real
+    ref = KD[f"{name}/out3"]
+    assert abs(want["total"].item() - ref[0]) <= 1e-5 * abs(ref[0])
+    # the options whose pass reads the teacher have no separate label pass
+    assert not KDLiteLoss(boundary_weight=2.0, num_classes=int(c)).to(dev).prepare_labels(lab)
+    assert not loss.prepare_labels(lab.cpu())
+
+
 def test_loss_components_differentiate_separately(dev):
     name = "c21_default"
     s0 = torch.from_numpy(KD[f"{name}/student"])

@@ -43,12 +43,14 @@ def run(loss_kind):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
         opt.zero_grad(set_to_none=True)
         ev[0].record()
+        if loss_kind == "fused_label_pass_aside":
+            fused.prepare_labels(lab)   # the loss's label pass on a stream of its own, beside the forwards
         s = student(img)
         ev[1].record()
         with torch.no_grad():
             t = teacher(img)
         ev[2].record()
-        loss = fused(s, t, lab)["total"] if loss_kind == "fused" else torch_loss(s, t, lab)
+        loss = fused(s, t, lab)["total"] if loss_kind.startswith("fused") else torch_loss(s, t, lab)
         ev[3].record()
         loss.backward()
         ev[4].record()
@@ -65,5 +67,6 @@ def run(loss_kind):
 
 res = {"config": {"model": "DeepLabV3Plus_resnet, every prunable group at 50 %", "batch": [args.batch, 3, args.size, args.size],
                   "classes": C, "dtype": "fp32 (the reference trains without autocast)", "steps": args.steps},
-       "fused_loss": run("fused"), "torch_op_loss": run("torch")}
+       "fused_loss": run("fused"), "fused_loss_label_pass_beside_the_forwards": run("fused_label_pass_aside"),
+       "torch_op_loss": run("torch")}
 print(json.dumps(res))

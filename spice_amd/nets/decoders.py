@@ -320,6 +320,13 @@ class SegmentationModel(nn.Module):
             units += list(self.decoder.prefix_units("decoder"))
         return units
 
+    def prefix_skip_units(self):
+        """Names of the units whose outputs may be read far behind the unit that follows them (the encoder's feature
+        maps); None when the encoder does not say.  The other units' outputs feed the next unit only."""
+        if not self.prefix_units() or not hasattr(self.encoder, "prefix_skip_units"):
+            return None
+        return list(self.encoder.prefix_skip_units("encoder"))
+
     def attach_tape(self, tape_pass) -> None:
         """Route the next forwards through `tape_pass` (a pass of a prefix.PrefixTape built from prefix_units());
         None detaches."""

@@ -120,6 +120,10 @@ class EfficientNetB3Encoder(nn.Module):
         self._unit_names = [n for n, _ in units]
         return units
 
+    def prefix_skip_units(self, prefix: str = "encoder"):
+        """The units whose outputs leave the encoder as feature maps: the stem and the last block of stages 1, 2, 4, 6."""
+        return [f"{prefix}.stem"] + [f"{prefix}.blocks.{i}.{len(self.blocks[i]) - 1}" for i in (1, 2, 4, 6)]
+
     def _stem(self, x):
         return self.act1(self.bn1(self.conv_stem(x)))
 

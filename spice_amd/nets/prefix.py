@@ -9,11 +9,20 @@ duration of a forward:
     recording   every unit runs; its output is kept            (the un-pruned network's forward of a sweep)
     replaying   units in front of `first` return what was kept; the others run   (a candidate's forward)
 
+    replaying up to a stop   the same, and the forward ends (StopForward) where unit `stop` would start: the caller
+                             has the outputs of the units in between (`keep`) and continues elsewhere - a captured
+                             launch graph of the unchanged units behind them, which reads its inputs from buffers of
+                             its own (`given`: what stands in for the recorded output of a unit in front of `first`)
+
 With no tape attached the forward is the plain one.  Unit outputs must never be written in place by a later unit.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+
+class StopForward(Exception):
+    """Raised by a pass at the unit it was told to stop in front of."""
 
 
 class PrefixTape:
@@ -39,6 +48,10 @@ class PrefixTape:
         """The first unit (in execution order) that runs any of the named modules."""
         return min((self.unit_of(n) for n in module_names), default=len(self.units))
 
+    def last_touched(self, module_names) -> int:
+        """The last unit that runs any of the named modules (len(self) when one of them lies behind the last unit)."""
+        return max((self.unit_of(n) for n in module_names), default=len(self.units))
+
     def complete(self) -> bool:
         return len(self.acts) == len(self.units)
 
@@ -52,30 +65,44 @@ class PrefixTape:
 
     def recorder(self) -> "_Pass":
         self.acts = {}
+        self.generation = getattr(self, "generation", 0) + 1   # launch graphs captured on the old activations are void
         return _Pass(self, 0, True)
 
-    def replay(self, first: int) -> "_Pass":
-        """A pass in which the units in front of index `first` return the recorded activations."""
-        return _Pass(self, first, False)
+    def replay(self, first: int, stop: Optional[int] = None, given: Optional[Dict[str, object]] = None,
+               keep: Optional[Dict[str, object]] = None) -> "_Pass":
+        """A pass in which the units in front of index `first` return the recorded activations (`given[name]` where
+        the caller supplies one); with `stop`, the forward ends with StopForward in front of unit `stop`, the outputs
+        of the units that ran left in `keep`."""
+        p = _Pass(self, first, False)
+        p.stop, p.given, p.keep = stop, given, keep
+        return p
 
 
 class _Pass:
     """What a network's forward sees: run(unit name, function, *arguments)."""
 
-    __slots__ = ("tape", "first", "recording", "reused")
+    __slots__ = ("tape", "first", "recording", "reused", "stop", "given", "keep", "graph")
 
     def __init__(self, tape: PrefixTape, first: int, recording: bool):
         self.tape, self.first, self.recording, self.reused = tape, first, recording, 0
+        self.stop = self.given = self.keep = self.graph = None
 
     def skips(self, name: str) -> bool:
         return not self.recording and self.tape.index[name] < self.first
 
     def run(self, name: str, fn: Callable, *args):
         tape = self.tape
-        if not self.recording and tape.index[name] < self.first:
+        k = tape.index[name]
+        if not self.recording and k < self.first:
             self.reused += 1
+            if self.given is not None and name in self.given:
+                return self.given[name]
             return tape.acts[name]
+        if self.stop is not None and k >= self.stop:
+            raise StopForward(name)
         out = fn(*args)
         if self.recording:
             tape.acts[name] = out
+        if self.keep is not None:
+            self.keep[name] = out
         return out

@@ -100,6 +100,11 @@ class ResNet50Encoder(nn.Module):
         self._unit_names = [n for n, _ in units]
         return units
 
+    def prefix_skip_units(self, prefix: str = "encoder"):
+        """The units whose outputs leave the encoder as feature maps (a decoder may read them far behind the unit that
+        follows): the stem and the last bottleneck of every stage."""
+        return [f"{prefix}.stem"] + [f"{prefix}.{stage}.{len(self._modules[stage]) - 1}" for stage in self._STAGES]
+
     def _stem(self, x):
         """(bn1(conv1(x)), its max-pooling).  On the inference path of a HIP device the batch-norm, the ReLU and the
         pooling are ONE launch over the convolution's result (ops.bn_act_maxpool: same values as the separate ops);

@@ -39,7 +39,7 @@ from . import ops
 from .engine import MagnitudeImportance, MagnitudePruner
 from .engine.pruner import SliceJob
 from .nets.layers import Conv1x1, StemConv7x7, conv3x3_served_by_library
-from .nets.prefix import PrefixTape
+from .nets.prefix import PrefixTape, StopForward
 
 DEFAULT_RATIOS = (0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9)
 
@@ -106,7 +106,15 @@ class SensitivitySweep:
         self._tape: Optional[PrefixTape] = None
         self._tape_src, self._tape_key = None, None
         self._first_unit: Dict[int, int] = {}
+        self._last_unit: Dict[int, int] = {}
         self.units_reused = 0   # units whose recorded activations stood in for a launch, over all candidates so far
+        #: the unchanged units BEHIND a candidate's group as one launch of a captured HIP graph (capture_suffix_graphs;
+        #: SPICE_SWEEP_GRAPHS=0: never)
+        self.suffix_graphs = os.environ.get("SPICE_SWEEP_GRAPHS", "1") != "0"
+        self._graphs: Dict[int, object] = {}   # first unit inside the graph -> _SuffixGraph
+        self._graphs_for = None                # what they were captured on
+        self._session_depth = 0
+        self.graph_launches = 0
 
     # -- cost of a candidate, for balancing ranks ---------------------------------------------
     #: share of a candidate's time that does not shrink with the network (host work per launch,
@@ -205,6 +213,17 @@ class SensitivitySweep:
             g = self.groups[self.candidates[index].group]
             k = 0 if tape is None else tape.first_touched(m.name for m in g.members)
             self._first_unit[index] = k
+        return k
+
+    def last_unit(self, index: int) -> int:
+        """Index of the last unit that runs a module of candidate `index`'s group (the number of units when one of
+        them lies behind the last unit): the units behind it run the un-pruned network's launches on new values."""
+        k = self._last_unit.get(index)
+        if k is None:
+            tape = self._ensure_tape()
+            g = self.groups[self.candidates[index].group]
+            k = 0 if tape is None else tape.last_touched(m.name for m in g.members)
+            self._last_unit[index] = k
         return k
 
     def teacher_forward(self, images: torch.Tensor) -> torch.Tensor:
@@ -348,11 +367,19 @@ class SensitivitySweep:
         fp32 parameters it has cast until its OUTERMOST region exits; the per-forward regions nest
         inside this one, so the ~70 unchanged convolution weights are cast once per sweep instead of
         once per candidate (the same fp16 values either way)."""
-        if self.autocast_dtype is None:
-            yield self
-        else:
-            with torch.autocast("cuda", dtype=self.autocast_dtype):
+        self._session_depth += 1
+        try:
+            if self.autocast_dtype is None:
                 yield self
+            else:
+                with torch.autocast("cuda", dtype=self.autocast_dtype):
+                    yield self
+        finally:
+            self._session_depth -= 1
+            if self._session_depth == 0:
+                # captured graphs read the fp16 copies of weights that autocast made inside this region and frees
+                # with it
+                self.drop_suffix_graphs()
 
     def warm_shapes(self, images: torch.Tensor, indices: Sequence[int]) -> int:
         """Run one throw-away convolution for every NEW convolution problem (changed channel
@@ -445,7 +472,15 @@ class SensitivitySweep:
         are made on the current stream between a join and a fork of their own."""
         lane = self if first_lane else self._lane_of(index)
         tape = self._tape_for(images)
-        replay = tape.replay(self.first_unit(index)) if tape is not None else None
+        replay = None
+        if tape is not None:
+            first, behind = self.first_unit(index), self.last_unit(index) + 1
+            graph = lane._graph_from(behind, tape, images) if (self.suffix_graphs and self._session_depth > 0) else None
+            if graph is not None:
+                replay = tape.replay(first, stop=behind, keep={})
+                replay.graph = graph
+            else:
+                replay = tape.replay(first)
         prepared = None
         if self.fused_head and self.prepared_teacher and teacher_logits is not None and kd_out is not None:
             prepared = self._teacher_parts(teacher_logits)
@@ -458,6 +493,85 @@ class SensitivitySweep:
         if replay is not None:
             self.units_reused += replay.reused
         return moved
+
+    # -- the unchanged units behind a candidate's group as one captured launch -------------------------------
+    def capture_suffix_graphs(self, images: torch.Tensor) -> Dict[str, float]:
+        """Capture, for every unit k the network names, the forward from unit k to the head's convolution as a HIP
+        graph on the un-pruned network (every lane its own, on its own copy).  A candidate whose group touches units
+        u .. k-1 then runs those eagerly on its sliced tensors and the rest as one graph launch: the host queues one
+        launch where it queued twenty-odd, which is what bounds the sweep (the host, not the device, sets the pace of
+        the candidate loop).  Needs teacher_forward(images) before (the graphs read the recorded activations of the
+        units in front of them where the candidate leaves them unchanged) and an enclosing session(); the graphs hold
+        until that session ends, the next teacher_forward, or drop_suffix_graphs().  Returns what it did."""
+        import time
+        info = {"graphs": 0, "seconds": 0.0, "lanes": len(self._lanes)}
+        tape = self._tape_for(images)
+        if (not self.suffix_graphs or tape is None or self._session_depth == 0 or not self.fused_head
+                or getattr(self.model, "prefix_skip_units", lambda: None)() is None):
+            return info
+        t0 = time.perf_counter()
+        self.join_lanes()
+        torch.cuda.synchronize(self.device)
+        for lane in self._lanes:
+            lane.fused_head = self.fused_head
+            for k in range(1, len(tape)):
+                if lane._capture_graph(k, tape, images) is not None:
+                    info["graphs"] += 1
+        torch.cuda.synchronize(self.device)
+        self.fork_lanes()
+        info["seconds"] = time.perf_counter() - t0
+        return info
+
+    def drop_suffix_graphs(self) -> None:
+        for lane in self._lanes:
+            lane._graphs, lane._graphs_for = {}, None
+
+    def _graph_from(self, k: int, tape: PrefixTape, images: torch.Tensor):
+        """The captured graph that starts at unit k, if there is one and it was captured on these activations."""
+        if not self._graphs or self._graphs_for != (id(tape), tape.generation, id(images), images._version):
+            return None
+        return self._graphs.get(k)
+
+    def _capture_graph(self, k: int, tape: PrefixTape, images: torch.Tensor):
+        key = (id(tape), tape.generation, id(images), images._version)
+        if self._graphs_for != key:
+            self._graphs, self._graphs_for = {}, key
+        names = [n for n, _ in tape.units]
+        skips = self.model.prefix_skip_units()
+        # what the captured units read of the units in front of them: the output of the unit just before, and the
+        # feature maps that left the encoder earlier
+        inputs = [names[k - 1]] + [n for n in skips if tape.index[n] < k - 1]
+        clone = lambda v: tuple(None if t is None else t.clone() for t in v) if isinstance(v, (tuple, list)) else v.clone()
+        statics = {n: clone(tape.acts[n]) for n in inputs}
+        stream = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(device=self.device)
+        graph = torch.cuda.CUDAGraph()
+        parts = None
+        try:
+            with torch.cuda.stream(stream):
+                self.model.attach_tape(tape.replay(k, given=statics))
+                try:
+                    self._forward_to_head(images)   # once eagerly: whatever the launches set up lazily exists before the capture
+                    side.wait_stream(stream)
+                    with torch.cuda.stream(side):
+                        graph.capture_begin()
+                        try:
+                            parts = self._forward_to_head(images)
+                        finally:
+                            graph.capture_end()
+                    stream.wait_stream(side)
+                finally:
+                    self.model.attach_tape(None)
+        except Exception as e:   # a launch that cannot be captured: this unit's candidates stay eager
+            import warnings
+            warnings.warn(f"no launch graph from unit {names[k]}: {e}")
+            torch.cuda.synchronize(self.device)
+            return None
+        if parts is None or parts[1] is None:
+            return None
+        g = _SuffixGraph(graph, statics, inputs, parts[0], parts[1])
+        self._graphs[k] = g
+        return g
 
     def _teacher_parts(self, teacher_logits: torch.Tensor):
         """(probabilities at the distillation temperature, per-pixel sum p ln p) of the teacher's logits, taken once
@@ -490,7 +604,22 @@ class SensitivitySweep:
             e0 = e1 = None
             if with_kd and kd_events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            parts = self._forward_to_head(images) if (with_kd and self.fused_head) else None
+            graph = getattr(replay, "graph", None) if replay is not None else None
+            if graph is not None and not (with_kd and self.fused_head):
+                raise RuntimeError("a pass that stops in front of a captured graph needs the one-launch tail")
+            if graph is not None:
+                # the units the group touches, then the unchanged rest of the network as ONE launch of the graph
+                # captured on the un-pruned network (the same kernels on the same shapes, reading this candidate's
+                # values from the graph's own input buffers)
+                try:
+                    self._forward_to_head(images)
+                    raise RuntimeError("the forward did not stop in front of the captured units")
+                except StopForward:
+                    pass
+                parts = graph.launch(replay.keep, replay.tape)
+                self.graph_launches += 1
+            else:
+                parts = self._forward_to_head(images) if (with_kd and self.fused_head) else None
             logits = None
             if parts is not None and parts[1] is None:
                 logits, parts = parts[0].contiguous(), None
@@ -600,6 +729,39 @@ class SensitivitySweep:
             for tb in ([table, kd] if with_kd else [table]):
                 sdist.all_reduce_sum_(tb)
         return {"confusion": table, "kd": kd, "miou": miou_from_confusion(table)}
+
+
+class _SuffixGraph:
+    """A captured forward from some unit to the head's convolution, its input buffers and its output."""
+
+    def __init__(self, graph, statics, inputs, low, up):
+        self.graph, self.statics, self.inputs, self.low, self.up = graph, statics, inputs, low, up
+        self.foreign = set()   # inputs whose buffer holds a candidate's values, not the un-pruned network's
+
+    @staticmethod
+    def _copy(dst, src) -> bool:
+        """False (nothing copied) where a shape differs: the candidate took channels out of this tensor, so every
+        module that reads it belongs to the candidate's group and ran eagerly - the captured units do not read it."""
+        pairs = list(zip(dst, src)) if isinstance(dst, (tuple, list)) else [(dst, src)]
+        if any(d is not None and (v is None or d.shape != v.shape) for d, v in pairs):
+            return False
+        for d, v in pairs:
+            if d is not None:
+                d.copy_(v)
+        return True
+
+    def launch(self, kept: Dict[str, object], tape: PrefixTape):
+        """Replay on the current stream with the outputs `kept` of the units a candidate ran itself; the other
+        inputs are the un-pruned network's (copied back only where the last candidate left its own)."""
+        for n in self.inputs:
+            if n in kept:
+                if self._copy(self.statics[n], kept[n]):
+                    self.foreign.add(n)
+            elif n in self.foreign:
+                self._copy(self.statics[n], tape.acts[n])
+                self.foreign.discard(n)
+        self.graph.replay()
+        return self.low, self.up
 
 
 def miou_from_confusion(table: torch.Tensor) -> torch.Tensor:

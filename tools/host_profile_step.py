@@ -13,15 +13,18 @@ model = nets.create_model("DeepLabV3Plus", "resnet50", bench.CLASSES).to(dev).ev
 images, labels = bench.build_inputs(dev)
 ignored = [m for m in model.segmentation_head.modules() if isinstance(m, torch.nn.Conv2d)]
 sw = SensitivitySweep(model, bench.CLASSES, DEFAULT_RATIOS, ignored_layers=ignored)
+sw.enable_lanes(int(os.environ.get("LANES", "2")))
 idx = list(range(0, len(sw.candidates), 5))[:80]
 sw.prepare(idx); sw.warm_shapes(images, idx)
 n = len(sw.candidates)
 table = torch.zeros(n, bench.CLASSES, bench.CLASSES, dtype=torch.int64, device=dev)
 kd = torch.zeros(n, 3, device=dev)
 with sw.session():
-    teacher = sw.forward(images).float().contiguous()
+    teacher = sw.teacher_forward(images).float().contiguous()   # (records the activations the candidates start from)
+    sw.fork_lanes()
     for i in idx[:20]:
         sw.evaluate(i, images, labels, teacher, table[i], kd[i])
+    sw.join_lanes()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in idx[20:]:
@@ -37,4 +40,5 @@ with sw.session():
     prof.disable()
     torch.cuda.synchronize()
 st = pstats.Stats(prof)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats("tottime").print_stats(40)
+st.sort_stats("cumtime").print_stats(30)

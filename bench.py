@@ -499,7 +499,7 @@ def whole_sweep(sweep, images, labels, dev, rank, world):
     elapsed = float(t.item())
     # per-rank split: own work (set-up of the share + candidates) against waiting for the slowest rank
     ph = sweep.last_share.get("phases", {})
-    keys = ["geometry_and_costs_s", "plans_s", "solver_lookups_s", "teacher_forward_s", "candidates_s"]
+    keys = ["geometry_and_costs_s", "plans_s", "solver_lookups_s", "teacher_forward_s", "graph_capture_s", "candidates_s"]
     share = torch.zeros(world, 4 + len(keys), device=dev, dtype=torch.float64)
     share[rank] = torch.tensor([sweep.last_share["candidates"], sweep.last_share["cost"], sweep.last_share["busy_s"], mine_s] +
                                [ph.get(k, 0.0) for k in keys], dtype=torch.float64)
@@ -740,13 +740,17 @@ def main():
         # the un-pruned network's forward: the teacher's logits and, with prefix reuse, every block's activations
         # (recorded either way, so that the A/B region behind the timed one can run both forms)
         want_reuse, sweep.prefix_reuse = sweep.prefix_reuse, True
-        teacher = sweep.teacher_forward(images).float().contiguous()
-        sweep.prefix_reuse = want_reuse
-        # one-time set-up like the launch of the process itself: the un-pruned network's forward from every block on
-        # as a captured HIP graph (they serve every candidate of every sweep on this geometry until the session ends)
+        # one-time set-up like the launch plans of the un-pruned network itself: its forward from every block on as a
+        # captured HIP graph - captured on ANOTHER batch of the same geometry; they serve every batch and every sweep
+        # on this geometry until the session ends (teacher_forward writes a new batch's activations to the same addresses)
         graph_info = {"graphs": 0, "seconds": 0.0}
         if want_reuse and not args.no_graphs:
-            graph_info = sweep.capture_suffix_graphs(images)
+            scratch = torch.randn_like(images)
+            sweep.teacher_forward(scratch)
+            graph_info = sweep.capture_suffix_graphs(scratch)
+            del scratch
+        teacher = sweep.teacher_forward(images).float().contiguous()
+        sweep.prefix_reuse = want_reuse
         table = torch.zeros(n_cand, CLASSES, CLASSES, dtype=torch.int64, device=dev)
         kd = torch.zeros(n_cand, 3, dtype=torch.float32, device=dev)
 
@@ -900,10 +904,12 @@ def main():
         "graphs_captured": graph_info["graphs"], "capture_s_outside_the_clock": round(graph_info["seconds"], 3),
         "lanes": graph_info.get("lanes", lanes), "graph_launches_in_all_regions": graph_launches,
         "note": "the un-pruned network's forward from every block on to the head's convolution, captured once per lane "
-                "after the teacher's forward; a candidate runs the blocks its group touches eagerly and the rest as one "
-                "graph launch (same kernels, same shapes: identical tables).  One-time set-up, valid for every sweep on "
-                "this batch geometry until the autocast session ends; value_without_suffix_graphs = the same K candidates, "
-                "plans made, every launch queued by the host",
+                "on another batch of the same geometry before the timed batch's teacher forward; a candidate runs the "
+                "blocks its group touches eagerly and the rest as one graph launch (same kernels, same shapes: identical "
+                "tables).  One-time set-up per geometry, valid for every batch and every sweep until the autocast session "
+                "ends; a single 414-candidate sweep that had to capture them itself would get the capture time back about "
+                "evenly (SensitivitySweep.run does not capture by default).  value_without_suffix_graphs = the same K "
+                "candidates, plans made, every launch queued by the host",
         **({"value_without_suffix_graphs": round(world * args.steps / elapsed_eager, 3),
             "confusion_matrices_identical_both_ways": same_tables_eager} if elapsed_eager else {})}
     result["dist"] = dist_info

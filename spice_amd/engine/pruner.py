@@ -99,7 +99,7 @@ class SliceJob:
         return out
 
     def build(self, idx_device: Optional[torch.Tensor] = None, idx_start: int = 0,
-              with_grads: bool = True) -> "SliceJob":
+              with_grads: bool = True, defer_upload: bool = False) -> "SliceJob":
         """Launch plan for the model as it stands now.  `idx_device` (int64) may be a shared buffer
         that already holds this job's index arrays, concatenated, from element `idx_start`."""
         if not self.entries:
@@ -152,10 +152,10 @@ class SliceJob:
             self.dst_offs.append(dpos)
             dpos += (d_rows * d_cols * max(inner, 1) + _ALIGN - 1) // _ALIGN * _ALIGN
         self.dst_elems = dpos
-        self.plan = ops.GatherPlan(specs, self.device)
+        self.plan = ops.GatherPlan(specs, self.device, defer_upload=defer_upload)   # (deferred: the caller sets plan.items)
         if idx_device is None:
             arrays = self.index_arrays()
-            idx_device = (torch.from_numpy(np.concatenate(arrays)).to(self.device) if arrays else
+            idx_device = (ops.upload(torch.from_numpy(np.concatenate(arrays)), self.device) if arrays else
                           torch.zeros(1, dtype=torch.int64, device=self.device))
         self.idx = idx_device
         return self

@@ -64,9 +64,29 @@ class PrefixTape:
         return total
 
     def recorder(self) -> "_Pass":
-        self.acts = {}
-        self.generation = getattr(self, "generation", 0) + 1   # launch graphs captured on the old activations are void
+        """A recording pass.  Where a unit's output has the layout of the one recorded before, the new values are
+        copied into the old tensor, so that the addresses of the recorded activations outlive the batch (launch graphs
+        captured on them stay valid); `generation` counts the times an address changed."""
+        self._old, self.acts = self.acts, {}
+        self.recordings = getattr(self, "recordings", 0) + 1
         return _Pass(self, 0, True)
+
+    def _store(self, name: str, out) -> None:
+        old = getattr(self, "_old", {}).pop(name, None)
+        a = out if isinstance(out, (tuple, list)) else (out,)
+        b = old if isinstance(old, (tuple, list)) else (old,)
+        same = old is not None and len(a) == len(b) and all(
+            (x is None and y is None) or (x is not None and y is not None and x.shape == y.shape and x.dtype == y.dtype
+                                          and x.device == y.device and y.is_contiguous() == x.is_contiguous())
+            for x, y in zip(a, b))
+        if same:
+            for x, y in zip(a, b):
+                if y is not None:
+                    y.copy_(x)
+            self.acts[name] = old
+        else:
+            self.acts[name] = out
+            self.generation = getattr(self, "generation", 0) + 1
 
     def replay(self, first: int, stop: Optional[int] = None, given: Optional[Dict[str, object]] = None,
                keep: Optional[Dict[str, object]] = None) -> "_Pass":
@@ -102,7 +122,7 @@ class _Pass:
             raise StopForward(name)
         out = fn(*args)
         if self.recording:
-            tape.acts[name] = out
+            tape._store(name, out)
         if self.keep is not None:
             self.keep[name] = out
         return out

@@ -31,6 +31,27 @@ def spice_ops():
 # work-item tables
 
 
+_UPLOAD_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def upload(host: torch.Tensor, device: torch.device) -> torch.Tensor:
+    """A small host tensor (launch plans, index lists) copied to the device while the current stream is busy: the copy
+    runs on a stream of its own that has nothing else queued (a copy from pageable memory returns when it has run; on
+    the current stream that would be behind everything launched so far), and the current stream is ordered behind it."""
+    device = torch.device(device)
+    if device.type != "cuda" or host.numel() == 0:
+        return host.to(device)
+    cur = torch.cuda.current_stream(device)
+    up = _UPLOAD_STREAMS.get(device.index)
+    if up is None:
+        up = _UPLOAD_STREAMS[device.index] = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(up):
+        out = host.to(device)
+    cur.wait_stream(up)
+    out.record_stream(cur)
+    return out
+
+
 def _upload_items(items, count: int, device: torch.device) -> torch.Tensor:
     """Copy a ctypes array of `count` fixed-size records into a device byte tensor."""
     nbytes = ctypes.sizeof(items._type_) * count
@@ -391,7 +412,9 @@ class GatherSpec:
 
 
 class GatherPlan:
-    def __init__(self, specs: Sequence[GatherSpec], device: torch.device):
+    def __init__(self, specs: Sequence[GatherSpec], device: torch.device, defer_upload: bool = False):
+        """defer_upload: the work items stay on the host (`items_host`, bytes) for the caller to upload together with
+        other plans' in one copy and hand back as `items`."""
         L = nat.lib()
         self.device = torch.device(device)
         self.specs = list(specs)
@@ -410,7 +433,14 @@ class GatherPlan:
         self.plan_flags = 0
         for k in range(self.n_items):
             self.plan_flags |= items[k].flags
-        self.items = _upload_items(items, self.n_items, self.device)
+        if defer_upload:
+            nbytes = ctypes.sizeof(nat.GatherItem) * self.n_items
+            self.items_host = torch.empty(max(nbytes, 1), dtype=torch.uint8)
+            if nbytes:
+                ctypes.memmove(self.items_host.data_ptr(), ctypes.addressof(items), nbytes)
+            self.items = None
+        else:
+            self.items = _upload_items(items, self.n_items, self.device)
         self.moved_elems = sum(s.dst_rows * s.dst_cols * s.inner for s in self.specs)
         self.index_elems = sum((s.dst_rows if s.idx_out_off >= 0 else 0) +
                                (s.dst_cols if s.idx_in_off >= 0 else 0) for s in self.specs)

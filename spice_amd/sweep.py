@@ -111,8 +111,15 @@ class SensitivitySweep:
         #: the unchanged units BEHIND a candidate's group as one launch of a captured HIP graph (capture_suffix_graphs;
         #: SPICE_SWEEP_GRAPHS=0: never)
         self.suffix_graphs = os.environ.get("SPICE_SWEEP_GRAPHS", "1") != "0"
+        #: SPICE_SWEEP_RUN_GRAPHS=1: run() captures them itself for a share of GRAPHS_FROM_CANDIDATES candidates and
+        #: more.  Off by default: 2 ms per graph and lane against 0.4 ms of host time per candidate that goes through
+        #: one is about even for ONE sweep of 414 candidates (0.09 s of capture, 0.41 -> 0.34 s of candidates); graphs
+        #: the caller captured in an enclosing session() are used either way
+        self.graphs_in_run = os.environ.get("SPICE_SWEEP_RUN_GRAPHS", "0") == "1"
         self._graphs: Dict[int, object] = {}   # first unit inside the graph -> _SuffixGraph
         self._graphs_for = None                # what they were captured on
+        self._graph_pool = None
+        self._weights_version = 0
         self._session_depth = 0
         self.graph_launches = 0
 
@@ -195,6 +202,7 @@ class SensitivitySweep:
     #: FIXED_COST_SHARE when candidates start at their group's first block (the fixed part no longer holds the
     #: unchanged layers' memory-bound kernels in front of it): tools/partition_balance.py
     FIXED_COST_SHARE_PREFIX = 0.45
+    GRAPHS_FROM_CANDIDATES = 150
 
     def _ensure_tape(self) -> Optional[PrefixTape]:
         """The tape of the primary network's units (None: the network names no units)."""
@@ -243,6 +251,9 @@ class SensitivitySweep:
         self._tape_src, self._tape_key = images, (images._version, tuple(images.shape))
         if not tape.complete():
             self._tape_src = None
+        for lane in self._lanes:   # weights changed in place since the graphs were captured: their fp16 copies moved
+            lane._weights_version = sum(int(p._version) for p in lane.model.parameters()) + \
+                sum(int(b._version) for b in lane.model.buffers())
         return logits
 
     def _tape_for(self, images: torch.Tensor) -> Optional[PrefixTape]:
@@ -343,7 +354,12 @@ class SensitivitySweep:
     def prepare(self, indices: Sequence[int]) -> None:
         if len(self._lanes) > 1:
             for k, lane in enumerate(self._lanes):
-                lane._prepare([i for i in indices if self.lane_index(i) == k])
+                mine = [i for i in indices if self.lane_index(i) == k]
+                if lane._stream is None:
+                    lane._prepare(mine)
+                else:
+                    with torch.cuda.stream(lane._stream):   # the stream that will read the plans
+                        lane._prepare(mine)
         else:
             self._prepare(indices)
 
@@ -356,10 +372,26 @@ class SensitivitySweep:
             for a in j.index_arrays():
                 arrays.append(a)
                 pos += len(a)
-        shared = (torch.from_numpy(np.concatenate(arrays)).to(self.device) if arrays else
+        shared = (ops.upload(torch.from_numpy(np.concatenate(arrays)), self.device) if arrays else
                   torch.zeros(1, dtype=torch.int64, device=self.device))
+        built = []
         for i, j, st in zip(todo, jobs, starts):
-            self.jobs[i] = j.build(idx_device=shared, idx_start=st, with_grads=False)
+            self.jobs[i] = j.build(idx_device=shared, idx_start=st, with_grads=False, defer_upload=True)
+            if j.plan is not None:
+                built.append(j.plan)
+        if built:
+            # every plan's work items in ONE copy to the device (each plan then holds a view of it)
+            offs, pos = [], 0
+            for p in built:
+                offs.append(pos)
+                pos += (p.items_host.numel() + 15) // 16 * 16
+            host = torch.zeros(pos, dtype=torch.uint8)
+            for p, o in zip(built, offs):
+                host[o:o + p.items_host.numel()] = p.items_host
+            dev_items = ops.upload(host, self.device)
+            for p, o in zip(built, offs):
+                p.items = dev_items[o:o + p.items_host.numel()]
+                p.items_host = None
 
     @contextlib.contextmanager
     def session(self):
@@ -444,7 +476,11 @@ class SensitivitySweep:
         # keyed by the tensor object (kept alive with its cast) and its version: an address alone can come back from
         # the allocator holding another batch
         if getattr(self, "_cast_src", None) is not images or self._cast_key != images._version:
-            self._cast = images.to(self.autocast_dtype)
+            old = getattr(self, "_cast", None)
+            if old is not None and old.shape == images.shape and old.dtype == self.autocast_dtype and old.device == images.device:
+                old.copy_(images)   # the same address for every batch of this geometry (captured graphs read it)
+            else:
+                self._cast = images.to(self.autocast_dtype)
             self._cast_src, self._cast_key = images, images._version
         return self._cast
 
@@ -524,16 +560,21 @@ class SensitivitySweep:
 
     def drop_suffix_graphs(self) -> None:
         for lane in self._lanes:
-            lane._graphs, lane._graphs_for = {}, None
+            lane._graphs, lane._graphs_for, lane._graph_pool = {}, None, None
 
     def _graph_from(self, k: int, tape: PrefixTape, images: torch.Tensor):
         """The captured graph that starts at unit k, if there is one and it was captured on these activations."""
-        if not self._graphs or self._graphs_for != (id(tape), tape.generation, id(images), images._version):
+        if not self._graphs or self._graphs_for != self._graph_key(tape, images):
             return None
         return self._graphs.get(k)
 
+    def _graph_key(self, tape: PrefixTape, images: torch.Tensor):
+        # the addresses the graphs hold: the recorded activations (their generation), the cast batch (its geometry),
+        # the weights (their versions, as of the last teacher_forward)
+        return (id(tape), getattr(tape, "generation", 0), tuple(images.shape), images.dtype, self._weights_version)
+
     def _capture_graph(self, k: int, tape: PrefixTape, images: torch.Tensor):
-        key = (id(tape), tape.generation, id(images), images._version)
+        key = self._graph_key(tape, images)
         if self._graphs_for != key:
             self._graphs, self._graphs_for = {}, key
         names = [n for n, _ in tape.units]
@@ -553,8 +594,12 @@ class SensitivitySweep:
                 try:
                     self._forward_to_head(images)   # once eagerly: whatever the launches set up lazily exists before the capture
                     side.wait_stream(stream)
+                    if self._graph_pool is None:
+                        # one memory pool for all graphs of a lane: they never run at the same time, and each keeps
+                        # its output tensor alive, so a later capture reuses only what earlier ones have let go of
+                        self._graph_pool = torch.cuda.graph_pool_handle()
                     with torch.cuda.stream(side):
-                        graph.capture_begin()
+                        graph.capture_begin(pool=self._graph_pool)
                         try:
                             parts = self._forward_to_head(images)
                         finally:
@@ -570,6 +615,7 @@ class SensitivitySweep:
         if parts is None or parts[1] is None:
             return None
         g = _SuffixGraph(graph, statics, inputs, parts[0], parts[1])
+        g.recording = getattr(tape, "recordings", 0)
         self._graphs[k] = g
         return g
 
@@ -714,6 +760,10 @@ class SensitivitySweep:
             del unpruned
             dev_sync()
             ph["teacher_forward_s"], t = time.perf_counter() - t, time.perf_counter()
+            if self.graphs_in_run and len(mine) >= self.GRAPHS_FROM_CANDIDATES:
+                self.capture_suffix_graphs(images)
+                dev_sync()
+                ph["graph_capture_s"], t = time.perf_counter() - t, time.perf_counter()
             self.fork_lanes()
             for lane in self._lanes[1:]:
                 # one forward of the un-pruned copy on the lane's stream: its allocator pool and its fp16 copies of the
@@ -737,6 +787,7 @@ class _SuffixGraph:
     def __init__(self, graph, statics, inputs, low, up):
         self.graph, self.statics, self.inputs, self.low, self.up = graph, statics, inputs, low, up
         self.foreign = set()   # inputs whose buffer holds a candidate's values, not the un-pruned network's
+        self.recording = None  # the recording of the un-pruned network the other buffers hold
 
     @staticmethod
     def _copy(dst, src) -> bool:
@@ -753,6 +804,9 @@ class _SuffixGraph:
     def launch(self, kept: Dict[str, object], tape: PrefixTape):
         """Replay on the current stream with the outputs `kept` of the units a candidate ran itself; the other
         inputs are the un-pruned network's (copied back only where the last candidate left its own)."""
+        if self.recording != getattr(tape, "recordings", 0):   # another batch since: every buffer is out of date
+            self.foreign = set(self.inputs)
+            self.recording = getattr(tape, "recordings", 0)
         for n in self.inputs:
             if n in kept:
                 if self._copy(self.statics[n], kept[n]):

@@ -627,6 +627,67 @@ def test_sweep_prefix_reuse_gives_the_tables_of_the_whole_forward(dev):
     assert first[0] == 0 and max(first) >= 17
 
 
+def test_sweep_suffix_graphs_give_the_tables_of_the_eager_forward(dev):
+    """The unchanged blocks BEHIND a candidate's group as one launch of a HIP graph captured on the un-pruned network:
+    every candidate of the 414-candidate sweep on the benchmark's batch, graphs captured on ANOTHER batch of the same
+    geometry (the recorded activations keep their addresses from batch to batch), against the same sweep with every
+    launch queued by the host: identical confusion matrices, losses to 1e-5.  The graphs go with the session."""
+    from spice_amd.sweep import DEFAULT_RATIOS
+    torch.manual_seed(1234)
+    model = nets.create_model("DeepLabV3Plus", "resnet50", 21).to(dev).eval()
+    ignored = [m for m in model.segmentation_head.modules() if isinstance(m, nn.Conv2d)]
+    x = torch.from_numpy(synth.normal(1234, 50, 8 * 3 * 512 * 512).reshape(8, 3, 512, 512)).to(dev)
+    other = torch.from_numpy(synth.normal(99, 50, 8 * 3 * 512 * 512).reshape(8, 3, 512, 512)).to(dev)
+    lab = torch.from_numpy(synth.label_map(1234, 8, 512, 512, 21, "blocky", ignore_share=0.05)).to(dev)
+    sweep = SensitivitySweep(model, 21, DEFAULT_RATIOS, ignored_layers=ignored)
+    assert sweep.enable_lanes(2) == 2
+    with sweep.session():
+        eager = sweep.run(x, lab)
+        assert sum(l.graph_launches for l in sweep._lanes) == 0
+        sweep.teacher_forward(other)
+        info = sweep.capture_suffix_graphs(other)
+        assert info["graphs"] == 2 * (len(sweep._tape) - 1)
+        got = sweep.run(x, lab)          # its teacher forward writes x's activations where the other batch's were
+        launches = sum(l.graph_launches for l in sweep._lanes)
+        assert launches > 100, launches
+        # a weight changed in place: the graphs (which hold the address of its old fp16 copy) are not used any more
+        with torch.no_grad():
+            model.encoder.layer3[0].conv1.weight.mul_(1.0)
+        again = sweep.run(x, lab, indices=list(range(0, 414, 40)))
+        assert sum(l.graph_launches for l in sweep._lanes) == launches
+    assert not sweep._graphs and not sweep._lanes[1]._graphs
+    assert torch.equal(got["confusion"], eager["confusion"])
+    assert torch.allclose(got["kd"], eager["kd"], rtol=1e-5, atol=1e-7)
+    pick = list(range(0, 414, 40))
+    assert torch.equal(again["confusion"][pick], eager["confusion"][pick])
+    # which candidates go through a graph: those whose group ends in front of the last unit
+    spans = [(sweep.first_unit(c.index), sweep.last_unit(c.index)) for c in sweep.candidates]
+    assert all(a <= b for a, b in spans) and any(b < len(sweep._tape) - 1 for _, b in spans)
+
+
+def test_sweep_suffix_graphs_on_a_pyramid_decoder(dev):
+    """FPN reads four of the encoder's feature maps far behind the blocks that made them: the graphs' inputs are the
+    unit just in front of them and every feature map that left the encoder earlier."""
+    torch.manual_seed(3)
+    model = nets.create_model("FPN", "resnet50", 7).to(dev).eval()
+    ignored = [m for m in model.segmentation_head.modules() if isinstance(m, nn.Conv2d)]
+    x = torch.randn(2, 3, 256, 256, device=dev)
+    lab = torch.from_numpy(synth.label_map(4, 2, 256, 256, 7, "blocky")).to(dev)
+    sweep = SensitivitySweep(model, 7, ratios=(0.3, 0.6), ignored_layers=ignored)
+    pick = list(range(0, len(sweep.candidates), 2))
+    with sweep.session():
+        eager = sweep.run(x, lab, indices=pick)
+        sweep.teacher_forward(x)
+        info = sweep.capture_suffix_graphs(x)
+        if info["graphs"] == 0:
+            pytest.skip("this network's tail does not go through the one-launch head")
+        got = sweep.run(x, lab, indices=pick)
+        assert sweep.graph_launches > 0
+    diff = (got["confusion"] - eager["confusion"]).abs().sum(dim=(1, 2))
+    assert int(diff.max()) <= 4          # (MIOpen serves part of this network and may pick another algorithm on a later call)
+    assert torch.allclose(got["kd"], eager["kd"], rtol=1e-3, atol=1e-5)
+
+
 @pytest.mark.parametrize("arch,enc", [("Unet", "timm-efficientnet-b3"), ("FPN", "resnet50"), ("Unet", "resnet50")])
 def test_sweep_prefix_reuse_on_the_other_networks(dev, arch, enc):
     """The encoders' and the U-Net decoder's units on networks whose forward goes through MIOpen (which may pick

@@ -141,6 +141,22 @@ def pmc_traffic(kernel_key):
     return None, None
 
 
+def rocprof_median_us(kernel_key):
+    """(median duration in us, file): the kernel's per-dispatch median in the newest committed rocprofv3 kernel trace of
+    this command with one candidate on the device at a time (the profiler serialises dispatches; this run's own figure
+    comes from HIP events)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "bench_lanes1_kernel_medians.txt")), reverse=True):
+        try:
+            with open(path) as f:
+                for line in f:
+                    if kernel_key in line:
+                        return float(line.split()[1]), os.path.relpath(path, ROOT)
+        except (OSError, ValueError, IndexError):
+            continue
+    return None, None
+
+
 def cpu_description():
     """(threads the CPU legs use, what the host is): the box's share of host cores is what OMP_NUM_THREADS says
     where it is set (os.cpu_count() names every core of the machine, many times the share of a one-GPU box)."""
@@ -865,6 +881,10 @@ def main():
                      "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4),
                      "traffic": pmc_traffic(kd_key)[0],
                      "traffic_source": pmc_traffic(kd_key)[1],
+                     "rocprofv3_median_us": rocprof_median_us(kd_key)[0],
+                     "rocprofv3_frac": (round(kd_bytes / rocprof_median_us(kd_key)[0] / 1e3 / PEAK_HBM_GBPS, 4)
+                                        if rocprof_median_us(kd_key)[0] else None),
+                     "rocprofv3_source": rocprof_median_us(kd_key)[1],
                      **({"note": kd_note} if kd_note else {}),
                      "algorithmic_bytes_per_launch": kd_bytes, "avg_launch_us": round(1e3 * kd_ms, 2),
                      "launches_timed": len(kd_events_alone),

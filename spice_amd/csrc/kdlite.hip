@@ -1340,10 +1340,16 @@ __global__ __launch_bounds__(THREADS, 4) void kdlite_head2_kernel(HeadArgs h) {
             if (i < total) pre[j] = load_chunk(src, i);
         }
     };
-    Rows cur = rows_of((int)blockIdx.x);
-    if ((int)blockIdx.x < n_tiles) request(cur);
+    // A workgroup takes a run of CONSECUTIVE tiles: neighbouring output rows lie under the same source rows (four of
+    // them at x4), so most tiles find their rows staged already - no staging, no barrier - and the source rows are
+    // fetched by one workgroup instead of by whichever four happen to take those tiles on four XCDs.
+    const int per_wg = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t_first = (int)blockIdx.x * per_wg, t_end = min(t_first + per_wg, n_tiles);
+    if (t_first < t_end) request(rows_of(t_first));
+    int s_n = -1, s_ylo = 0, s_yhi = 0, s_xlo = 0;   // the rows the stage holds
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = t_first; tile < t_end; ++tile) {
+        const Rows cur = rows_of(tile);
         const int n = cur.n;
         const int px_first = cur.px_first;
         const int r = px_first + tid;   // the lane's pixel inside the image
@@ -1376,9 +1382,10 @@ __global__ __launch_bounds__(THREADS, 4) void kdlite_head2_kernel(HeadArgs h) {
 
         const int oy_first = cur.oy_first, y_lo = cur.y_lo, y_hi = cur.y_hi, x_lo = cur.x_lo;
         const int rows = y_hi - y_lo + 1;
-        __syncthreads();   // whoever still reads the previous tile's rows (first time: the cleared histogram, the padding)
-        {
-            // The tile's source chunks were requested while the previous tile was worked on (the first tile's before
+        const bool fresh = !(n == s_n && y_lo == s_ylo && y_hi == s_yhi && x_lo == s_xlo);   // uniform
+        if (fresh) {
+            __syncthreads();   // whoever still reads the staged rows (first time: the cleared histogram, the padding)
+            // The tile's source chunks were requested while the tiles before were worked on (the first tile's before
             // the loop): converted and stored now.  Chunk i = (k, c) with the class fastest: a wave's stores fall on
             // consecutive banks.
             const int total = C * rows * chunks_per_row;
@@ -1391,27 +1398,32 @@ __global__ __launch_bounds__(THREADS, 4) void kdlite_head2_kernel(HeadArgs h) {
                 const __half *src = h.low + ((long long)n * C * h.in_h + y_lo) * h.in_w + x_lo;
                 for (int i = tid + NPRE * THREADS; i < total; i += THREADS) deposit_chunk(i, load_chunk(src, i));
             }
+            s_n = n, s_ylo = y_lo, s_yhi = y_hi, s_xlo = x_lo;
+            __syncthreads();
         }
-        __syncthreads();
-        if (tile + (int)gridDim.x < n_tiles) {   // the next tile's source chunks: on their way while this tile is worked on
-            cur = rows_of(tile + (int)gridDim.x);
-            request(cur);
+        if (tile + 1 < t_end) {
+            // the next tile's source chunks, if it lies under other rows: on their way while this tile is worked on
+            // (the registers that hold them are free: whatever was requested before has been stored)
+            const Rows nx = rows_of(tile + 1);
+            if (!(nx.n == s_n && nx.y_lo == s_ylo && nx.y_hi == s_yhi && nx.x_lo == s_xlo)) request(nx);
         }
         if constexpr (LOSS) {
-            for (int j = tid; j < rows * WC; j += THREADS) {
-                const f32x4_t *p = reinterpret_cast<const f32x4_t *>(stage + j * CPAD);
-                // NaN-propagating maxima (v_maximum3_f32: no canonicalising moves); a NaN here sends the pixels around it
-                // to the exact walk
-                float m = kNegFill;
+            if (fresh) {
+                for (int j = tid; j < rows * WC; j += THREADS) {
+                    const f32x4_t *p = reinterpret_cast<const f32x4_t *>(stage + j * CPAD);
+                    // NaN-propagating maxima (v_maximum3_f32: no canonicalising moves); a NaN here sends the pixels around it
+                    // to the exact walk
+                    float m = kNegFill;
 #pragma unroll
-                for (int s4 = 0; s4 < CPAD / 4; ++s4) {
-                    const f32x4_t x = p[s4];
-                    m = __builtin_elementwise_maximum(__builtin_elementwise_maximum(m, x.x), x.y);
-                    m = __builtin_elementwise_maximum(__builtin_elementwise_maximum(m, x.z), x.w);
+                    for (int s4 = 0; s4 < CPAD / 4; ++s4) {
+                        const f32x4_t x = p[s4];
+                        m = __builtin_elementwise_maximum(__builtin_elementwise_maximum(m, x.x), x.y);
+                        m = __builtin_elementwise_maximum(__builtin_elementwise_maximum(m, x.z), x.w);
+                    }
+                    smax[j] = m;
                 }
-                smax[j] = m;
+                __syncthreads();
             }
-            __syncthreads();
         }
         if (!live) continue;
         int oy;

@@ -18,7 +18,7 @@ cp "$S/kbench_fwd/kb_kernel_stats.csv" "$D/kbench_forward_kernel_stats.csv"
 cp "$S/kbench_fwd_medians.txt" "$D/kbench_forward_kernel_medians.txt"
 grep "^{" "$S/kbench_fwd.log" > "$D/kbench_forward_kernels_under_rocprof.jsonl" || true
 cp "$S/pmc_traffic.json" "$S/pmc_traffic_small_cases.json" "$S/pmc_traffic_forward_kernels.json" "$D/"
-for f in conv1x1_pairs_fused_vs_two_launches.jsonl conv3x3_library_vs_miopen.jsonl bench_n1.json; do
+for f in conv1x1_pairs_fused_vs_two_launches.jsonl conv3x3_library_vs_miopen.jsonl bench_n1.json bench_n1_no_graphs.json host_profile_step.txt kd_finetune_step.json bench_2ranks_gloo_one_gpu.json; do
     [ -s "$S/$f" ] && cp "$S/$f" "$D/$f"
 done
 echo copied

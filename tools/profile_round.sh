@@ -15,7 +15,8 @@ python3 tools/trace_medians.py "$OUT/kbench_fwd" > "$OUT/kbench_fwd_medians.txt"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o bench -- python3 bench.py --no-cpu-baseline > "$OUT/bench_line.json" 2> "$OUT/bench.err"
 python3 tools/trace_medians.py "$OUT/bench" > "$OUT/bench_medians.txt"
 # ... and with one candidate on the device at a time: every kernel's duration by itself, and the step breakdown
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_lanes1" -o bench -- python3 bench.py --no-cpu-baseline --lanes 1 > "$OUT/bench_lanes1_line.json" 2> "$OUT/bench_lanes1.err"
+# (every launch queued by the host, so that the trace holds a candidate's launches in the order they were issued)
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_lanes1" -o bench -- python3 bench.py --no-cpu-baseline --lanes 1 --no-graphs > "$OUT/bench_lanes1_line.json" 2> "$OUT/bench_lanes1.err"
 python3 tools/trace_medians.py "$OUT/bench_lanes1" > "$OUT/bench_lanes1_medians.txt"
 python3 tools/stepbreakdown.py "$(find "$OUT/bench_lanes1" -name "*kernel_trace.csv" | head -1)" > "$OUT/sweep_step_breakdown.txt"
 # 3. HBM traffic: one counter per pass, nothing else traced
@@ -36,5 +37,9 @@ timeout -k 10 300 python3 tools/conv1x1_bench.py --plain > "$OUT/conv1x1_pairs_f
 timeout -k 10 300 python3 tools/conv3x3_bench.py > "$OUT/conv3x3_library_vs_miopen.jsonl" 2>/dev/null
 timeout -k 10 100 python3 tools/conv7x7_bench.py >> "$OUT/conv3x3_library_vs_miopen.jsonl" 2>/dev/null
 timeout -k 10 300 python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
+timeout -k 10 300 python3 bench.py --no-graphs --no-strong-block --no-cpu-baseline > "$OUT/bench_n1_no_graphs.json" 2> /dev/null
+timeout -k 10 300 python3 tools/host_profile_step.py > "$OUT/host_profile_step.txt" 2> /dev/null
+timeout -k 10 300 python3 tools/ftbench.py --steps 10 2> /dev/null | tail -1 > "$OUT/kd_finetune_step.json"
+SPICE_DIST_BACKEND=gloo timeout -k 10 400 python3 bench.py --gpus 2 --steps 20 --warmup 4 --no-cpu-baseline > "$OUT/bench_2ranks_gloo_one_gpu.json" 2> /dev/null
 echo convolution benches done
 echo profile pass done

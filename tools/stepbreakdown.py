@@ -9,14 +9,15 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # a candidate ends in one launch of the head kernel (up-sampling + loss + arg-max histogram), or, on the three-launch
 # route, of the plain loss kernel
-kd = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("void spice::kdlite_head_kernel")]
+kd = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(("void spice::kdlite_head_kernel", "void spice::kdlite_head2_kernel"))
+      and ", true" in r["Kernel_Name"].split("(")[0]]   # (the loss forms; the arg-max-only form belongs to the evaluation loops)
 if len(kd) <= steps:
     kd = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("void spice::kdlite_main_kernel<4, false, false, false>")]
 ts = [int(rows[i]["Start_Timestamp"]) for i in kd]
 gaps = [(ts[k + 1] - ts[k]) / 1e6 for k in range(len(ts) - 1)]
 best, s = (0, 0), None
 for k, g in enumerate(gaps + [0]):
-    if 2.0 < g < 12:
+    if 0.3 < g < 12:
         if s is None:
             s = k
     else:

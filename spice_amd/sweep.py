@@ -199,9 +199,10 @@ class SensitivitySweep:
         return out
 
     # -- the un-pruned network's activations in front of a candidate's first block ---------------------------
-    #: FIXED_COST_SHARE when candidates start at their group's first block (the fixed part no longer holds the
-    #: unchanged layers' memory-bound kernels in front of it): tools/partition_balance.py
-    FIXED_COST_SHARE_PREFIX = 0.45
+    #: FIXED_COST_SHARE when candidates start at their group's first block: the time of a candidate is then nearly
+    #: proportional to the multiply-accumulates it still runs (fit on MI355X: 0.17 ms + 1.40 ms x relative
+    #: multiply-accumulates, residual 0.08 ms of 0.16-1.9 ms): tools/partition_balance.py
+    FIXED_COST_SHARE_PREFIX = 0.11
     GRAPHS_FROM_CANDIDATES = 150
 
     def _ensure_tape(self) -> Optional[PrefixTape]:

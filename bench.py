@@ -803,6 +803,13 @@ def main():
             same_tables_eager = bool(torch.equal(table_g, table[timed]))
     n_warm = len(sweep._warmed)
     kd_events_alone = kd_events
+    head_lows = []
+    real_head = ops.sweep_head
+
+    def spy_head(low, *a, **k):   # the head's inputs of the candidates below, for the back-to-back launches behind them
+        head_lows.append(low.clone())
+        return real_head(low, *a, **k)
+    ops.sweep_head = spy_head
     if lanes > 1:
         # With several candidates in flight the loss kernel shares the device with the other lane's convolutions and
         # its duration says how they split the memory system, not how good the kernel is: the same K candidates once
@@ -814,6 +821,7 @@ def main():
                 sweep.evaluate(todo[i], images, labels, teacher, table[todo[i]], kd[todo[i]], first_lane=True)
         torch.cuda.synchronize()
         kd_events_alone, sweep.kd_events = sweep.kd_events, None
+    ops.sweep_head = real_head
     kd_ms_shared = float(np.mean([a.elapsed_time(b) for a, b in kd_events])) if kd_events else float("nan")
     kd_ms = float(np.mean([a.elapsed_time(b) for a, b in kd_events_alone])) if kd_events_alone else float("nan")
     # the kernel those events bracket: the candidate's tail in one launch (up-sampling + loss + arg-max histogram over
@@ -844,6 +852,35 @@ def main():
         kd_kernel = "spice::kdlite_main_kernel<4,false,false,false> (one launch per spice_kdlite_forward call)"
         kd_key = "spice::kdlite_main_kernel<4, false, false, false>"
         kd_note = None
+    # A pair of events per launch adds the events' own trips to the figure (5-7 us on a 50 us kernel).  The duration
+    # the roofline uses: the head launches of those K candidates again, on their own fp16 head outputs, back to back
+    # between ONE pair of events (the teacher's probabilities rotate over three copies, 3 x 176 MB, so that no launch
+    # finds them in the 256 MB memory-side cache); median of five such runs / K.
+    kd_ms_pairs = kd_ms
+    back_to_back = False
+    if one_launch_head and head_lows and sweep._teacher_prepared is not None and lanes > 1:
+        pr = [sweep._teacher_prepared] + [tuple(t.clone() for t in sweep._teacher_prepared[:2]) for _ in range(2)]
+        scratch_conf = torch.zeros(CLASSES, CLASSES, dtype=torch.int64, device=dev)
+        scratch_out = torch.zeros(3, dtype=torch.float32, device=dev)
+
+        def heads_once():
+            for j, low in enumerate(head_lows):
+                t = pr[j % 3]
+                real_head(low, t[0], labels, scratch_conf, align_corners=True, out=scratch_out, scale_factor=4.0,
+                          teacher_hneg=t[1], **sweep.kd)
+        heads_once()
+        torch.cuda.synchronize()
+        runs = []
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            heads_once()
+            b.record()
+            b.synchronize()
+            runs.append(a.elapsed_time(b) / len(head_lows))
+        kd_ms = float(np.median(runs))
+        back_to_back = True
+        del pr
     achieved = kd_bytes / kd_ms / 1e6
     result = {
         "metric": "sensitivity-sweep candidates/sec",
@@ -887,11 +924,19 @@ def main():
                      "rocprofv3_source": rocprof_median_us(kd_key)[1],
                      **({"note": kd_note} if kd_note else {}),
                      "algorithmic_bytes_per_launch": kd_bytes, "avg_launch_us": round(1e3 * kd_ms, 2),
-                     "launches_timed": len(kd_events_alone),
+                     "launches_timed": len(head_lows) * 5 if back_to_back else len(kd_events_alone),
                      "measured": ("HIP events round the K launches of the timed region" if lanes == 1 else
+                                  "behind the timed region: the head launches of the same K candidates (their own fp16 "
+                                  "head outputs, the batch's labels and prepared teacher, the teacher rotating over three "
+                                  "copies) back to back between ONE pair of HIP events, median of 5 runs / K" if back_to_back else
                                   "HIP events round the launches of the same K candidates evaluated once more behind the "
                                   "timed region, one candidate on the device at a time (as `--lanes 1` times them "
                                   "inside it)"),
+                     **({"one_event_pair_per_launch": {
+                         "avg_launch_us": round(1e3 * kd_ms_pairs, 2),
+                         "frac": round(kd_bytes / kd_ms_pairs / 1e6 / PEAK_HBM_GBPS, 4),
+                         "note": "the same K candidates evaluated once more, one at a time, each head launch between "
+                                 "its own pair of events: the events' own trips are in the figure"}} if back_to_back else {}),
                      "in_timed_region": {"avg_launch_us": round(1e3 * kd_ms_shared, 2),
                                          "frac": round(kd_bytes / kd_ms_shared / 1e6 / PEAK_HBM_GBPS, 4),
                                          "candidates_in_flight": lanes,

@@ -612,6 +612,11 @@ def main():
     ap.add_argument("--fp32-forward", action="store_true", help="forward without fp16 autocast")
     ap.add_argument("--no-graphs", action="store_true",
                     help="every launch of a candidate queued by the host (no captured HIP graphs of the unchanged blocks)")
+    ap.add_argument("--plan-chunk", type=int, default=8,
+                    help="--plans chunks: launch plans of this many candidates at a time, in front of the first of them")
+    ap.add_argument("--plans", default="inloop", choices=["upfront", "inloop", "chunks"],
+                    help="launch plans of the timed candidates: all before the first evaluation, or each in front of its "
+                         "candidate's launches (both inside the clock)")
     ap.add_argument("--warm-mode", default="upfront", choices=["upfront", "none"],
                     help="how the solver lookups for new convolution shapes are taken out of the candidate loop")
     ap.add_argument("--no-tune", action="store_true", help="skip the MIOpen find-database warm-up of the backbone")
@@ -719,11 +724,16 @@ def main():
     sweep.warm_shapes(images, warm_list)
 
     host_s = [0.0]
+    prep_split = [0.0]
+    # plans in front of each candidate's launches unless a candidate may bring MIOpen a new problem (then plans and
+    # look-ups up front, as SensitivitySweep.run does)
+    plans_mode = "upfront" if sweep.may_need_solver_lookups(images) else args.plans
 
     def timed_region(first_time):
         """K candidates, wall-clock, barrier and device synchronisation on both sides; the first time it holds ALL
-        per-candidate work of its K candidates: launch plans and index upload, the solver lookups for their new
-        convolution shapes (up front, while nothing is queued), evaluation, the all-reduce of the tables."""
+        per-candidate work of its K candidates: launch plans and their upload (in front of each candidate's launches,
+        or all up front together with the solver lookups for new convolution shapes where the network has
+        convolutions on MIOpen), evaluation, the all-reduce of the tables."""
         table.zero_()   # (outside the clock) every row is its owner's alone before the all-reduce sums the ranks' tables
         kd.zero_()
         sweep.fork_lanes()
@@ -731,13 +741,16 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         prep = 0.0
-        if first_time:
+        if first_time and plans_mode == "upfront":
             sweep.prepare(timed_list)
+            prep_split[0] = time.perf_counter() - t0
             if args.warm_mode == "upfront":
                 sweep.warm_shapes(images, timed_list)
             prep = time.perf_counter() - t0
         moved = 0
         for i in range(args.warmup, total_steps):
+            if first_time and plans_mode == "chunks" and (i - args.warmup) % args.plan_chunk == 0:
+                sweep.prepare(todo[i:min(i + args.plan_chunk, total_steps)])
             with sweep.lane_context(todo[i]):
                 table[todo[i]].zero_()
             moved += sweep.evaluate(todo[i], images, labels, teacher, table[todo[i]], kd[todo[i]])
@@ -942,7 +955,10 @@ def main():
                                          "candidates_in_flight": lanes,
                                          "note": "the kernel's launches overlap the other lane's convolutions and share "
                                                  "the memory system with them"}},
-        "setup": {"miopen_find_db_warmup_s": round(tune_s, 1), "timed_prepare_s": round(prep_s, 4),
+        "setup": {"miopen_find_db_warmup_s": round(tune_s, 1), "timed_prepare_s": round(prep_s, 4), "timed_prepare_plans_s": round(prep_split[0], 4),
+                  "plans": {"upfront": "all before the first evaluation", "chunks": f"{args.plan_chunk} candidates at a time",
+                            "inloop": "each in front of its candidate's launches, uploaded by a launch "
+                                      "(spice_gather_upload)"}[plans_mode],
                   "host_queued_everything_after_ms_per_step": {"timed_region": round(1e3 * host_first / args.steps, 3),
                                                                "same_candidates_again": round(1e3 * host_again / args.steps, 3),
                                                                "note": "wall time until the host has launched the region's last "

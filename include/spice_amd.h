@@ -322,6 +322,15 @@ int spice_gather_run(const float *src_base, float *dst_base, const int64_t *idx_
                      const spice_gather_item *d_items, int64_t n_items, int32_t plan_flags,
                      void *stream);
 
+/* A plan's work items and index lists (or any bytes) from page-locked host memory to the device as a LAUNCH on
+ * `stream`: a kernel reads the host memory through its device mapping, so the call returns at once however much the
+ * stream already holds (a copy command from page-locked memory keeps the caller until the stream has run that far).
+ * The sweep makes the plans of the next candidates while the device works on the current ones (reference:
+ * pruning/sensitivity.py builds every candidate's pruner inside its loop, :120-160).  dst: device memory; src_host:
+ * page-locked, device-readable host memory that stays untouched until the launch has run; both 16-byte aligned,
+ * nbytes a multiple of 16.  SPICE_ERR_ARG otherwise. */
+int spice_gather_upload(void *dst, const void *src_host, int64_t nbytes, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * (5) Bilinear up-sampling of NCHW planes (the models' decoder and head).
  *

@@ -103,6 +103,7 @@ SIGNATURES = {
                                                 c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "spice_gather_plan": (c_int64, [POINTER(GatherDesc), c_int32, POINTER(GatherItem), c_int64]),
     "spice_gather_run": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "spice_gather_upload": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "spice_bn_act": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                c_int64, c_int64, c_int64, c_int32, c_void_p]),
     "spice_bn_act_dual": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float,

@@ -337,3 +337,34 @@ extern "C" int spice_gather_run(const float *src_base, float *dst_base, const in
     SPICE_LAUNCH_CHECK();
     return SPICE_OK;
 }
+
+// ---- launch plans to the device without a copy command ----
+//
+// A copy command from page-locked host memory, queued on a stream that already holds launches, keeps the calling
+// thread until the stream has run that far (measured on MI355X / ROCm 7: up to 5 ms per call inside a candidate
+// loop that is a few milliseconds ahead of the device).  A kernel that reads the host memory through its device
+// mapping is a launch like any other: the host moves on at once, and the bytes cross the bus when the stream
+// gets there.
+namespace spice {
+__global__ __launch_bounds__(256) void gather_upload_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, long long n16) {
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += step) dst[i] = src[i];
+}
+}  // namespace spice
+
+extern "C" int spice_gather_upload(void *dst, const void *src_host, int64_t nbytes, void *stream) {
+    if (nbytes < 0) return SPICE_ERR_ARG;
+    if (nbytes == 0) return SPICE_OK;
+    if (!dst || !src_host || (nbytes & 15) || !aligned16(dst) || !aligned16(src_host)) return SPICE_ERR_ARG;
+    void *mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, const_cast<void *>(src_host), 0) != hipSuccess || mapped == nullptr) {
+        (void)hipGetLastError();
+        return SPICE_ERR_ARG;   // not page-locked memory the device can read
+    }
+    const long long n16 = nbytes >> 4;
+    const unsigned blocks = (unsigned)((n16 + 255) / 256 < 1024 ? (n16 + 255) / 256 : 1024);
+    hipLaunchKernelGGL(spice::gather_upload_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<uint4 *>(dst), static_cast<const uint4 *>(mapped), n16);
+    SPICE_LAUNCH_CHECK();
+    return SPICE_OK;
+}

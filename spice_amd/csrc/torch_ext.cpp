@@ -125,6 +125,15 @@ void gather_run(std::vector<Tensor> srcs, Tensor dst, const Tensor &idx, const T
              "spice_gather_run");
 }
 
+void gather_upload(Tensor dst, const Tensor &src) {
+    check_dev(dst, "dst", at::kByte);
+    TORCH_CHECK_VALUE(src.device().is_cpu() && src.scalar_type() == at::kByte && src.is_contiguous() && src.is_pinned(),
+                      "src must be a contiguous uint8 tensor in page-locked host memory");
+    TORCH_CHECK_VALUE(dst.numel() == src.numel() && dst.numel() % 16 == 0, "dst and src must hold the same multiple of 16 bytes");
+    c10::DeviceGuard guard(dst.device());
+    check_rc(spice_gather_upload(dst.data_ptr(), src.data_ptr(), dst.numel(), current_stream(dst)), "spice_gather_upload");
+}
+
 // ---- (3) confusion --------------------------------------------------------------------------
 
 void check_conf(const Tensor &conf, int64_t num_classes) {
@@ -793,6 +802,7 @@ TORCH_LIBRARY(spice, m) {
           "Tensor folds, int n_folds, int mode) -> ()", &importance_cols_run);
     m.def("gather_run(Tensor[] srcs, Tensor(a!) dst, Tensor idx, Tensor items, int n_items, int plan_flags) -> ()",
           &gather_run);
+    m.def("gather_upload(Tensor(a!) dst, Tensor src) -> ()", &gather_upload);
     m.def("confusion_update(Tensor(a!) conf, Tensor preds, Tensor target, int num_classes, Tensor(b!) workspace) -> ()",
           &confusion_update);
     m.def("confusion_update_static(Tensor(a!) conf, Tensor preds, Tensor target, int num_classes, "

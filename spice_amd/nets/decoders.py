@@ -292,7 +292,8 @@ class FPNDecoder(nn.Module):
 class SegmentationHead(nn.Sequential):
     def __init__(self, in_ch: int, classes: int, kernel: int, upsampling: int):
         up = BilinearUp(scale_factor=upsampling) if upsampling > 1 else nn.Identity()
-        super().__init__(nn.Conv2d(in_ch, classes, kernel, padding=kernel // 2), up, nn.Identity())
+        conv = layers.Conv1x1Bias(in_ch, classes) if kernel == 1 else nn.Conv2d(in_ch, classes, kernel, padding=kernel // 2)
+        super().__init__(conv, up, nn.Identity())
 
 
 class SegmentationModel(nn.Module):

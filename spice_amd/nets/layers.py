@@ -184,6 +184,36 @@ class Conv1x1(nn.Conv2d):
         return super().forward(x)
 
 
+class Conv1x1Bias(nn.Conv2d):
+    """nn.Conv2d(in_ch, out_ch, 1) with its bias: the convolution of a segmentation head.  On fp16 activations
+    (autocast) under no_grad on a HIP device, planes of a multiple of 8 pixels, the forward is one launch of the
+    library's matrix-core kernel with the bias added where a batch-norm's shift would be (MIOpen serves this
+    convolution through a solver it looks up per channel count, and a sweep candidate that prunes the layer in front
+    brings a new count).  In every other situation torch's conv2d runs."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__(in_channels, out_channels, 1, bias=True)
+
+    def served_by_library(self, x_dtype: torch.dtype, height: int, width: int) -> bool:
+        """Whether forward() on a plane of this size is a launch of the library (no MIOpen call, no solver lookup)."""
+        b = self._parameters["bias"]
+        return (_LIBRARY_FORWARD and b is not None and b.dtype == torch.float32 and self.groups == 1
+                and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0)
+                and (height * width) % 8 == 0
+                and (x_dtype == torch.float16 or
+                     (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16))
+                and _within_kernel_offsets(self.in_channels, self.out_channels, 1, height, width, 1))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if (not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4
+                and self.served_by_library(x.dtype, x.shape[2], x.shape[3])):
+            if x.dtype != torch.float16:
+                x = x.to(torch.float16)   # what autocast does to a convolution's input
+            if x.is_contiguous():
+                return ops.conv1x1_bias(x, _fp16_matrix(self.weight), self._parameters["bias"])
+        return super().forward(x)
+
+
 def _plain_inference_norm(bn: nn.BatchNorm2d) -> bool:
     # parameters and buffers straight from their tables (nn.Module's attribute fallback is several dictionary probes
     # per name; this runs once per batch-norm per forward)

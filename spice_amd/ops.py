@@ -12,6 +12,7 @@ import ctypes
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from . import _native as nat
@@ -50,6 +51,98 @@ def upload(host: torch.Tensor, device: torch.device) -> torch.Tensor:
     cur.wait_stream(up)
     out.record_stream(cur)
     return out
+
+
+class _StagingRing:
+    """Page-locked host memory for small uploads queued on ONE stream: two halves, a half is written again only after
+    the copies queued from it have run (an event recorded when the writer moved on to the other half)."""
+
+    HALF = 1 << 21
+
+    def __init__(self):
+        self.buf = torch.empty(2 * self.HALF, dtype=torch.uint8, pin_memory=True)
+        self.half, self.pos = 0, 0
+        self.left = [None, None]   # the event behind the last copy out of each half
+
+    def take(self, nbytes: int, stream: "torch.cuda.Stream") -> torch.Tensor:
+        nbytes = (nbytes + 255) // 256 * 256
+        if self.pos + nbytes > self.HALF:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            self.left[self.half] = ev
+            self.half, self.pos = 1 - self.half, 0
+            if self.left[self.half] is not None:
+                self.left[self.half].synchronize()
+                self.left[self.half] = None
+        start = self.half * self.HALF + self.pos
+        self.pos += nbytes
+        return self.buf[start:start + nbytes]
+
+
+_STAGING: Dict[tuple, _StagingRing] = {}
+
+
+def _device_bytes(size: int, device: torch.device) -> torch.Tensor:
+    return torch.empty(size, dtype=torch.uint8, device=device)
+
+
+def _queue_copy(dst: torch.Tensor, src: torch.Tensor) -> None:
+    # a launch, not a copy command: a copy command from page-locked memory keeps the caller until the stream has run
+    # that far (up to 5 ms inside a candidate loop that is ahead of the device)
+    spice_ops().gather_upload(dst, src)
+
+
+def upload_staged(parts: Sequence[np.ndarray], device: torch.device) -> List[torch.Tensor]:
+    """Small host arrays (index lists, work-item tables) to the device as ONE copy queued on the CURRENT stream, in
+    order with the launches that read them: the bytes go through page-locked staging memory, so the copy is
+    asynchronous (a copy from pageable memory returns only once it has run, i.e. behind everything the stream already
+    holds) and the host moves on at once.  Returns one device tensor per part (views of one allocation, each starting
+    on a 256-byte boundary, typed like its part)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("upload_staged needs a HIP device")
+    parts = [a if a.flags.c_contiguous else np.ascontiguousarray(a) for a in parts]
+    stream = torch.cuda.current_stream(device)
+    key = (device.index, stream.cuda_stream)
+    out: List[Optional[torch.Tensor]] = [None] * len(parts)
+    group, size = [], 0
+
+    def flush():
+        nonlocal group, size
+        if not group:
+            return
+        ring = _STAGING.get(key)
+        if ring is None:
+            ring = _STAGING[key] = _StagingRing()
+        seg = ring.take(size, stream)
+        host = seg.numpy()
+        dev = _device_bytes(size, device)
+        pos = 0
+        for k in group:
+            a = parts[k]
+            n = int(a.nbytes)
+            if n:
+                host[pos:pos + n] = a.reshape(-1).view(np.uint8)
+            piece = dev[pos:pos + n]
+            out[k] = piece if a.dtype == np.uint8 else piece.view(_TORCH_OF_NUMPY[a.dtype.type])
+            pos += (n + 255) // 256 * 256
+        _queue_copy(dev, seg[:size])
+        group, size = [], 0
+
+    for k, a in enumerate(parts):
+        n = (int(a.nbytes) + 255) // 256 * 256
+        if n > _StagingRing.HALF:   # too large for the staging memory: a copy of its own
+            out[k] = upload(torch.from_numpy(a), device)
+            continue
+        if size + n > _StagingRing.HALF:
+            flush()
+        group.append(k)
+        size += n
+    flush()
+    return out
+
+
+_TORCH_OF_NUMPY = {np.int64: torch.int64, np.int32: torch.int32, np.float32: torch.float32, np.uint8: torch.uint8}
 
 
 def _upload_items(items, count: int, device: torch.device) -> torch.Tensor:
@@ -642,6 +735,29 @@ def conv1x1_bn_act(x: torch.Tensor, weight2d: torch.Tensor, bn: "torch.nn.BatchN
     args = (x, weight2d, *_bn_parts(bn), residual, *r, relu, route, out, *p, pre_relu)
     if _conv_probe is not None:
         return _probed("matrix_core_pair", _conv1x1_bn_fn, args, x, weight2d.shape[0], weight2d.shape[1], residual)
+    return _conv1x1_bn_fn(*args)
+
+
+_UNIT_NORMS: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def conv1x1_bias(x: torch.Tensor, weight2d: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """weight2d[Cout, Cin] @ x[n][Cin, H*W] + bias for fp16 NCHW x and an fp32 bias: a 1x1 convolution with bias (a
+    segmentation head's) as ONE launch of the matrix-core kernel, the bias taking the place of a batch-norm's shift
+    (mean 0, variance 1, weight 1, eps 0: the product, rounded to fp16 as a stored convolution result is, plus the bias
+    in fp32, rounded to fp16).  The plane must be a multiple of 8 pixels."""
+    global _conv1x1_bn_fn
+    if _conv1x1_bn_fn is None:
+        _conv1x1_bn_fn = spice_ops().conv1x1_bn_act
+    key = (x.device, int(weight2d.shape[0]))
+    unit = _UNIT_NORMS.get(key)
+    if unit is None:
+        unit = _UNIT_NORMS[key] = (torch.zeros(key[1], dtype=torch.float32, device=x.device),
+                                   torch.ones(key[1], dtype=torch.float32, device=x.device))
+    none5 = (None, None, None, None, 0.0)
+    args = (x, weight2d, unit[0], unit[1], unit[1], bias, 0.0, None, *none5, False, 1, None, *none5, False)
+    if _conv_probe is not None:
+        return _probed("matrix_core_pair", _conv1x1_bn_fn, args, x, weight2d.shape[0], weight2d.shape[1], None)
     return _conv1x1_bn_fn(*args)
 
 

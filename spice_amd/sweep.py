@@ -38,9 +38,10 @@ from . import dist as sdist
 from . import ops
 from .engine import MagnitudeImportance, MagnitudePruner
 from .engine.pruner import SliceJob
-from .nets.layers import Conv1x1, StemConv7x7, conv3x3_served_by_library
+from .nets.layers import Conv1x1, Conv1x1Bias, StemConv7x7, conv3x3_served_by_library
 from .nets.prefix import PrefixTape, StopForward
 
+_LATER = object()   # SliceJob.build: the index buffer is handed over after the build
 DEFAULT_RATIOS = (0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9)
 
 
@@ -89,6 +90,7 @@ class SensitivitySweep:
                                                  self._weight_share_cost(g, n)))
         self.jobs: Dict[int, SliceJob] = {}
         # when set to a list, evaluate() appends a (start, end) HIP event pair around each KD-Lite launch
+        self.plans_up_front = os.environ.get("SPICE_SWEEP_PLANS_UP_FRONT", "0") == "1"   # run(): every plan before the first candidate
         self.kd_events: Optional[list] = None
         #: the candidate's up-sampling, loss and arg-max histogram in one launch where the network's head allows
         #: it (SPICE_SWEEP_FUSED_HEAD=0: always the three separate launches)
@@ -281,6 +283,27 @@ class SensitivitySweep:
                 h.remove()
         self._geometry_for = shape
 
+    def may_need_solver_lookups(self, images: torch.Tensor) -> bool:
+        """Whether a candidate of this sweep can bring MIOpen a convolution problem it has not seen: true as soon as
+        one convolution a channel group touches goes to torch's conv2d on this batch geometry (depthwise ones aside:
+        they do not go through MIOpen).  The library's own kernels take every channel count, so where they serve all
+        those convolutions un-pruned they serve every candidate's too, and nothing needs looking up ahead."""
+        self._ensure_geometry(images)
+        for g in self.groups:
+            for m in g.members:
+                mod = m.module
+                if not isinstance(mod, nn.Conv2d) or mod not in self._geometry or mod.groups == mod.in_channels > 1:
+                    continue
+                (_, _, h, w), in_dtype = self._geometry[mod]
+                dt = self.autocast_dtype or in_dtype
+                if isinstance(mod, (Conv1x1, Conv1x1Bias, StemConv7x7)):
+                    if mod.served_by_library(dt, h, w):
+                        continue
+                elif conv3x3_served_by_library(mod, dt, h, w):
+                    continue
+                return True
+        return False
+
     # -- host preparation for a set of candidates: plans + one shared index upload
     # -- lanes: further copies of the network, each with its own launch plans and its own stream -------------
     def enable_lanes(self, count: int) -> int:
@@ -373,26 +396,18 @@ class SensitivitySweep:
             for a in j.index_arrays():
                 arrays.append(a)
                 pos += len(a)
-        shared = (ops.upload(torch.from_numpy(np.concatenate(arrays)), self.device) if arrays else
-                  torch.zeros(1, dtype=torch.int64, device=self.device))
-        built = []
+        # the plans first (host work only), then the index lists and every plan's work items as ONE asynchronous
+        # copy on the current stream - the stream that will launch them
         for i, j, st in zip(todo, jobs, starts):
-            self.jobs[i] = j.build(idx_device=shared, idx_start=st, with_grads=False, defer_upload=True)
-            if j.plan is not None:
-                built.append(j.plan)
-        if built:
-            # every plan's work items in ONE copy to the device (each plan then holds a view of it)
-            offs, pos = [], 0
-            for p in built:
-                offs.append(pos)
-                pos += (p.items_host.numel() + 15) // 16 * 16
-            host = torch.zeros(pos, dtype=torch.uint8)
-            for p, o in zip(built, offs):
-                host[o:o + p.items_host.numel()] = p.items_host
-            dev_items = ops.upload(host, self.device)
-            for p, o in zip(built, offs):
-                p.items = dev_items[o:o + p.items_host.numel()]
-                p.items_host = None
+            self.jobs[i] = j.build(idx_device=_LATER, idx_start=st, with_grads=False, defer_upload=True)
+        built = [j.plan for j in jobs if j.plan is not None]
+        parts = [np.concatenate(arrays) if arrays else np.zeros(1, dtype=np.int64)]
+        parts += [p.items_host.numpy() for p in built]
+        dev = ops.upload_staged(parts, self.device)
+        for j in jobs:
+            j.idx = dev[0]
+        for p, items in zip(built, dev[1:]):
+            p.items, p.items_host = items, None
 
     @contextlib.contextmanager
     def session(self):
@@ -455,7 +470,7 @@ class SensitivitySweep:
             key = (n, cin, h, w, cout, groups, mod.kernel_size, mod.stride, mod.padding, mod.dilation)
             if key in self._warmed or groups == cin:  # depthwise convolutions do not go through MIOpen
                 continue
-            if isinstance(mod, (Conv1x1, StemConv7x7)) and mod.served_by_library(self.autocast_dtype or in_dtype, h, w):
+            if isinstance(mod, (Conv1x1, Conv1x1Bias, StemConv7x7)) and mod.served_by_library(self.autocast_dtype or in_dtype, h, w):
                 continue  # a plain matrix product: no solver lookup to get out of the way
             if conv3x3_served_by_library(mod, self.autocast_dtype or in_dtype, h, w):
                 continue  # the library's own 3x3 kernel (the bottlenecks' convolutions): likewise
@@ -741,12 +756,24 @@ class SensitivitySweep:
         mine = [indices[k] for k in parts[rank]]
         dev_sync()
         ph["geometry_and_costs_s"], t = time.perf_counter() - t, time.perf_counter()
-        self.prepare(mine)
-        dev_sync()
-        ph["plans_s"], t = time.perf_counter() - t, time.perf_counter()
-        self.warm_shapes(images, mine)
-        dev_sync()
-        ph["solver_lookups_s"], t = time.perf_counter() - t, time.perf_counter()
+        # Launch plans: made in front of each candidate's launches (evaluate does that for a candidate it has no plan
+        # for), while the device works on the candidates before - their bytes travel as a launch, so the host is not
+        # held.  Only where a candidate may bring MIOpen a new convolution problem are plans and look-ups made up
+        # front: a look-up synchronises the stream, which is cheap while nothing is queued.
+        # (without captured graphs for the unchanged units the host, not the device, sets the pace of the loop: plans
+        # made in a row up front then cost less than plans made between the launches)
+        graphs = self.suffix_graphs and (any(l._graphs for l in self._lanes) or
+                                         (self.graphs_in_run and len(mine) >= self.GRAPHS_FROM_CANDIDATES))
+        if self.plans_up_front or not graphs or self.may_need_solver_lookups(images):
+            self.prepare(mine)
+            dev_sync()
+            ph["plans_s"], t = time.perf_counter() - t, time.perf_counter()
+            self.warm_shapes(images, mine)
+            dev_sync()
+            ph["solver_lookups_s"], t = time.perf_counter() - t, time.perf_counter()
+        else:
+            ph["plans_s"] = ph["solver_lookups_s"] = 0.0
+            t = time.perf_counter()
         self.last_share = {"candidates": len(mine), "cost": float(sum(all_costs[i] for i in mine)), "phases": ph}
         c = self.num_classes
         table = torch.zeros(n, c, c, dtype=torch.int64, device=self.device)

@@ -717,3 +717,34 @@ def test_sweep_prefix_reuse_on_the_other_networks(dev, arch, enc):
         y1 = model(x)
         model.attach_tape(None)
     assert tape.complete() and torch.allclose(y0, y1, rtol=1e-4, atol=1e-5)
+
+
+def test_sweep_plans_made_between_the_launches(dev):
+    """With captured graphs run() makes a candidate's launch plan in front of its launches (uploaded by a launch of
+    spice_gather_upload, which does not hold the host) instead of all plans up front: same tables; and the choice
+    falls back to plans + solver look-ups up front where a candidate may bring MIOpen a new convolution problem."""
+    torch.manual_seed(7)
+    model = nets.create_model("DeepLabV3Plus", "resnet50", 21).to(dev).eval()
+    ignored = [m for m in model.segmentation_head.modules() if isinstance(m, nn.Conv2d)]
+    x = torch.randn(2, 3, 256, 256, device=dev)
+    lab = torch.from_numpy(synth.label_map(5, 2, 256, 256, 21, "blocky", ignore_share=0.05)).to(dev)
+    tables = []
+    for up_front in (True, False):
+        sweep = SensitivitySweep(model, 21, ratios=(0.25, 0.5, 0.75), ignored_layers=ignored)
+        sweep.enable_lanes(2)
+        sweep.plans_up_front = up_front
+        assert not sweep.may_need_solver_lookups(x)        # every convolution a group touches is the library's
+        with sweep.session():
+            sweep.teacher_forward(x)
+            assert sweep.capture_suffix_graphs(x)["graphs"] > 0
+            assert not sweep.jobs and not sweep._lanes[1].jobs
+            out = sweep.run(x, lab)
+            plans_s = sweep.last_share["phases"]["plans_s"]
+            assert (plans_s > 0.0) == up_front
+            assert len(sweep.jobs) + len(sweep._lanes[1].jobs) == len(sweep.candidates)
+            assert sum(l.graph_launches for l in sweep._lanes) > 0
+        tables.append(out)
+    assert torch.equal(tables[0]["confusion"], tables[1]["confusion"])
+    assert torch.equal(tables[0]["kd"], tables[1]["kd"])
+    fp32 = SensitivitySweep(model, 21, ratios=(0.5,), ignored_layers=ignored, autocast_dtype=None)
+    assert fp32.may_need_solver_lookups(x)                  # the fp32 forward runs on torch's convolutions

@@ -988,3 +988,63 @@ def test_deeplab_decoder_without_concatenation_pass(dev):
         finally:
             decoders._writes_in_place = keep
     assert direct.dtype == torch.float16 and torch.equal(direct, concatenated)
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(256, 21, 32, 32), (205, 21, 16, 24), (77, 5, 8, 8), (26, 19, 12, 10)])
+def test_head_convolution_with_bias_in_one_launch(dev, cin, cout, h, w):
+    """Conv1x1Bias under fp16 autocast: the matrix-core kernel's product rounded to fp16, plus the bias in fp32,
+    rounded to fp16 - bit for bit what the bias-free product and a separate addition give; within fp16 rounding of
+    torch's conv2d (which adds the bias before its one rounding); torch's conv2d itself where the plane is not a
+    multiple of 8 pixels or gradients are wanted."""
+    from spice_amd.nets import layers
+    torch.manual_seed(cin + cout)
+    conv = layers.Conv1x1Bias(cin, cout).to(dev)
+    conv.bias.data.normal_(0.0, 0.5)
+    x = torch.randn(2, cin, h, w, device=dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        assert conv.served_by_library(x.dtype, h, w) == ((h * w) % 8 == 0)
+        got = conv(x)
+        plain = ops.conv1x1_f16(x.half(), conv.weight.detach().half().reshape(cout, cin))
+        want = (plain.float() + conv.bias.view(1, -1, 1, 1)).half()
+        there = torch.nn.functional.conv2d(x, conv.weight, conv.bias)
+    assert got.dtype == torch.float16 and got.shape == (2, cout, h, w)
+    if (h * w) % 8 == 0:
+        assert torch.equal(got, want)
+    step = 2e-3 * max(1.0, float(there.float().abs().max()))
+    assert float((got.float() - there.float()).abs().max()) <= step
+    with torch.autocast("cuda", dtype=torch.float16):   # gradients wanted: torch's convolution
+        y = conv(x)
+    assert y.requires_grad and torch.equal(y.detach(), there)
+
+
+def test_plan_upload_as_a_launch(dev):
+    """spice_gather_upload through the raw C-ABI and ops.upload_staged above it: bytes from page-locked host memory
+    arrive on the device in stream order without a copy command; several typed parts in one launch, more than the
+    staging memory holds in a row (both halves reused), a part larger than a half by an ordinary copy."""
+    L = nat.lib()
+    host = torch.arange(4096, dtype=torch.int64).pin_memory()
+    dst = torch.zeros(4096, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    assert L.spice_gather_upload(dst.data_ptr(), host.data_ptr(), host.numel() * 8, st) == 0
+    assert torch.equal(dst.cpu(), host)
+    assert L.spice_gather_upload(dst.data_ptr(), host.data_ptr(), 0, st) == 0
+    assert L.spice_gather_upload(dst.data_ptr(), host.data_ptr(), 24, st) != 0                       # not whole 16-byte words
+    assert L.spice_gather_upload(dst.data_ptr() + 8, host.data_ptr(), 64, st) != 0                   # misaligned
+    pageable = torch.arange(64, dtype=torch.int64)
+    assert L.spice_gather_upload(dst.data_ptr(), pageable.data_ptr(), 512, st) != 0                  # not page-locked
+    with pytest.raises(ValueError):
+        ops.spice_ops().gather_upload(dst.view(torch.uint8), pageable.view(torch.uint8))
+    rng = np.random.default_rng(3)
+    parts = [rng.integers(0, 1 << 40, 1001).astype(np.int64), rng.integers(0, 255, 77).astype(np.uint8),
+             np.zeros(0, dtype=np.int64), rng.standard_normal(300).astype(np.float32)]
+    got = ops.upload_staged(parts, dev)
+    for a, t in zip(parts, got):
+        assert t.is_cuda and tuple(t.shape) == a.shape and np.array_equal(t.cpu().numpy(), a)
+    kept = []
+    for k in range(24):     # 24 x 300 KB: both halves of the staging memory are written several times over
+        a = rng.integers(0, 1 << 30, 300 * 128).astype(np.int64)
+        kept.append((a, ops.upload_staged([a], dev)[0]))
+    big = rng.integers(0, 255, (1 << 21) + 4096).astype(np.uint8)
+    kept.append((big, ops.upload_staged([big], dev)[0]))
+    for a, t in kept:
+        assert np.array_equal(t.cpu().numpy(), a)

@@ -1366,16 +1366,11 @@ __global__ __launch_bounds__(THREADS, 4) void kdlite_head2_kernel(HeadArgs h) {
             const __amdgpu_buffer_rsrc_t planes = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float *>(a.t + (long long)n * C * a.HW), 0, C * HW * 4, 0x00020000);
             const int rb = (live ? r : 0) * 4;
-#ifndef SPICE_HEAD2_TIMING_NO_TEACHER
 #pragma unroll
             for (int c = 0; c < CPAD; c += 2) {
                 tp[c >> 1].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(planes, rb, c * HW * 4, 2 /* non-temporal */));
                 tp[c >> 1].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(planes, rb, (c + 1) * HW * 4, 2));
             }
-#else
-#pragma unroll
-            for (int c = 0; c < CPAD; c += 2) tp[c >> 1] = (f32x2_t)(0.01f * (float)c);
-#endif
             if (live) hn = __builtin_nontemporal_load(h.hneg + (long long)n * a.HW + r);
         }
         if (live) lab = a.labels[(long long)n * a.HW + r];
@@ -1472,10 +1467,6 @@ __global__ __launch_bounds__(THREADS, 4) void kdlite_head2_kernel(HeadArgs h) {
                 arg = take ? c : arg;
             }
         }
-#ifdef SPICE_HEAD2_TIMING_NO_TAIL
-        acc[0] += best + (float)arg + zs + z1 + ps;
-        continue;
-#endif
         // one unsigned comparison decides "a class"
         const int id = ((unsigned long long)lab < (unsigned long long)C) ? (int)lab : ((LOSS && lab == a.ignore_index) ? -1 : -2);
         if (id >= 0) atomicAdd(&hist[id * C + arg], 1u);

@@ -8,7 +8,7 @@ mkdir -p "$D"
 cp "$S/bench_line.json" "$D/bench_n1_under_rocprof.json"
 cp "$S/bench/bench_kernel_stats.csv" "$D/bench_kernel_stats.csv"
 cp "$S/bench_medians.txt" "$D/bench_kernel_medians.txt"
-cp "$S/sweep_step_breakdown.txt" "$D/"
+cp "$S/sweep_step_breakdown.txt" "$S/sweep_step_breakdown_graphs.txt" "$D/"
 cp "$S/bench_lanes1_line.json" "$D/bench_n1_lanes1_under_rocprof.json"
 cp "$S/bench_lanes1/bench_kernel_stats.csv" "$D/bench_lanes1_kernel_stats.csv"
 cp "$S/bench_lanes1_medians.txt" "$D/bench_lanes1_kernel_medians.txt"

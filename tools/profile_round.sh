@@ -16,9 +16,14 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 python3 tools/trace_medians.py "$OUT/bench" > "$OUT/bench_medians.txt"
 # ... and with one candidate on the device at a time: every kernel's duration by itself, and the step breakdown
 # (every launch queued by the host, so that the trace holds a candidate's launches in the order they were issued)
+export SPICE_BENCH_MARK=1
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_lanes1" -o bench -- python3 bench.py --no-cpu-baseline --lanes 1 --no-graphs > "$OUT/bench_lanes1_line.json" 2> "$OUT/bench_lanes1.err"
 python3 tools/trace_medians.py "$OUT/bench_lanes1" > "$OUT/bench_lanes1_medians.txt"
 python3 tools/stepbreakdown.py "$(find "$OUT/bench_lanes1" -name "*kernel_trace.csv" | head -1)" > "$OUT/sweep_step_breakdown.txt"
+# ... and the same with the captured graphs (the graphs' kernels appear in the trace like any other launch)
+timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d "$OUT/bench_lanes1_graphs" -o bench -- python3 bench.py --no-cpu-baseline --no-kernel-table --no-strong-block --lanes 1 > "$OUT/bench_lanes1_graphs_line.json" 2> "$OUT/bench_lanes1_graphs.err"
+python3 tools/stepbreakdown.py "$(find "$OUT/bench_lanes1_graphs" -name "*kernel_trace.csv" | head -1)" > "$OUT/sweep_step_breakdown_graphs.txt"
+unset SPICE_BENCH_MARK
 # 3. HBM traffic: one counter per pass, nothing else traced
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 tools/kbench.py --iters 6 > "$OUT/pmc_fetch.log" 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 tools/kbench.py --iters 6 > "$OUT/pmc_write.log" 2>&1

@@ -1901,9 +1901,11 @@ static int head_prepare(HeadArgs &ha, const void *low, const int64_t *labels, in
         chunks = c * lds_rows * (win / 8);
         if (chunks >= (1 << 20)) return SPICE_ERR_UNSUPPORTED;   // the float reciprocals that split a chunk number stay exact
         max_per_cu = (int)(kLdsPerCu / (lds_bytes + 512));
-        // resident workgroups per compute unit: 512 lanes at four waves per SIMD (the loss form's registers) are two,
-        // the arg-max form's registers allow three
-        const int reg_limit = (loss ? 2 : 3) * (512 / head2_threads());
+        // workgroups per compute unit: 512 lanes at four waves per SIMD (the loss form's registers) are two; the
+        // arg-max form's registers allow three, but two are faster (29.6 against 30.9 us at [8,21,128,128] -> 512 x 512:
+        // fewer rows for the tail to fold), and a second round of workgroups costs either form more than its tail
+        // hidden behind the first round saves (loss form: 51.7 / 61.1 / 59.3 us with 2 / 3 / 4 per compute unit)
+        const int reg_limit = 2 * (512 / head2_threads());
         if (max_per_cu > reg_limit) max_per_cu = reg_limit;
         if (max_per_cu < 1) max_per_cu = 1;
     } else {

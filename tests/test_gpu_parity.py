@@ -232,6 +232,7 @@ def test_kdlite_golden(dev, name, want_grad):
 def test_kdlite_config3_size(dev, variant):
     """[8,21,512,512], T=4, alpha=0.7: HIP vs the fp32 op-sequence oracle and the fp64 value."""
     n, c, h, w = 8, 21, 512, 512
+    bad_before = ops.kdlite_bad_label_count(dev)   # (a count per process: tests before this one may have fed bad labels)
     s, t = synth.logits_pair(1234, n, c, h, w)
     lab = synth.label_map(1234, n, h, w, c, "blocky" if variant != "default" else "uniform")
     kw = dict(temperature=4.0, alpha=0.7)
@@ -254,7 +255,7 @@ def test_kdlite_config3_size(dev, variant):
     g = grad.cpu()
     assert (g - g_ref).abs().max().item() <= REL * g_ref.abs().max().item()
     assert int(sums[1].item()) == int((lab != 255).sum())
-    assert ops.kdlite_bad_label_count(dev) == 0
+    assert ops.kdlite_bad_label_count(dev) == bad_before
 
 
 @pytest.mark.parametrize("c,hw,variant", [(24, (20, 28), "default"), (25, (20, 28), "default"), (40, (9, 13), "boundary_conf"),

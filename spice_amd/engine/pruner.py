@@ -169,8 +169,8 @@ class SliceJob:
         dst = torch.empty(max(self.dst_elems, 1), dtype=torch.float32, device=self.device)
         self.plan.run(self.srcs, dst, self.idx)
         if keep_undo:
-            self._undo = ([(o, a, getattr(o, a)) for o, a, _, _ in self.entries],
-                          [(m, {k: getattr(m, k) for k in upd}) for m, upd in self.attr_updates],
+            self._undo = ([(o, a, o._parameters[a] if a in o._parameters else o._buffers[a]) for o, a, _, _ in self.entries],
+                          [(m, {k: m.__dict__[k] for k in upd}) for m, upd in self.attr_updates],
                           [(g, g.size) for g, _ in self.decisions])
 
         def view(k):
@@ -181,17 +181,18 @@ class SliceJob:
         for k, (owner, attr, is_grad) in enumerate(self.sources):
             if is_grad:
                 continue
-            old = getattr(owner, attr)
-            if isinstance(old, nn.Parameter):
+            # parameters, buffers and the modules' size attributes go straight into their tables: nn.Module's
+            # __setattr__ walks several of them per call, and a sweep makes ~20 such writes per candidate and undoes them
+            old = owner._parameters.get(attr)
+            if old is not None:
                 p = nn.Parameter(view(k), requires_grad=old.requires_grad)
                 if (id(owner), attr) in new_grads:
                     p.grad = new_grads[(id(owner), attr)]
-                setattr(owner, attr, p)
+                owner._parameters[attr] = p
             else:
                 owner._buffers[attr] = view(k)
         for m, upd in self.attr_updates:
-            for key, val in upd.items():
-                setattr(m, key, val)
+            m.__dict__.update(upd)
         for g, pruned in self.decisions:
             g.size -= len(pruned)
         return self.plan.algorithmic_bytes()
@@ -202,12 +203,11 @@ class SliceJob:
         tensors, attrs, sizes = self._undo
         for owner, attr, old in tensors:
             if isinstance(old, nn.Parameter):
-                setattr(owner, attr, old)
+                owner._parameters[attr] = old
             else:
                 owner._buffers[attr] = old
         for m, upd in attrs:
-            for key, val in upd.items():
-                setattr(m, key, val)
+            m.__dict__.update(upd)
         for g, size in sizes:
             g.size = size
         self._undo = None

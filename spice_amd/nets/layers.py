@@ -331,13 +331,17 @@ class ConvBnAct(nn.Sequential):
         super().__init__(conv, bn)
 
     def forward(self, x, out: Optional[torch.Tensor] = None):
-        conv = self[0]
+        # (the sub-modules from their table: nn.Sequential's indexing walks an iterator per call)
+        mods = self._modules
+        conv, bn = mods["0"], mods["1"]
         if type(conv) is Conv1x1:
-            return conv1x1_bn(conv, self[1], x, out=out)
-        if isinstance(conv, nn.Sequential) and len(conv) == 2 and type(conv[1]) is Conv1x1:
-            return conv1x1_bn(conv[1], self[1], conv[0](x), out=out)   # separable: depthwise, then the pointwise pair
+            return conv1x1_bn(conv, bn, x, out=out)
+        if isinstance(conv, nn.Sequential) and len(conv._modules) == 2:
+            inner = conv._modules
+            if type(inner.get("1")) is Conv1x1 and "0" in inner:
+                return conv1x1_bn(inner["1"], bn, inner["0"](x), out=out)   # separable: depthwise, then the pointwise pair
         if type(conv) is nn.Conv2d and conv.kernel_size == (3, 3):
-            y = conv3x3_bn(conv, self[1], x)   # None where the library's 3x3 kernel does not apply
+            y = conv3x3_bn(conv, bn, x)   # None where the library's 3x3 kernel does not apply
             if y is not None:
                 return _into(out, y)
-        return _into(out, self[1](conv(x)))
+        return _into(out, bn(conv(x)))

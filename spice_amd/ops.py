@@ -55,7 +55,7 @@ def upload(host: torch.Tensor, device: torch.device) -> torch.Tensor:
 
 class _StagingRing:
     """Page-locked host memory for small uploads queued on ONE stream: two halves, a half is written again only after
-    the copies queued from it have run (an event recorded when the writer moved on to the other half)."""
+    the launches that read it have run (an event recorded when the writer moved on to the other half)."""
 
     HALF = 1 << 21
 
@@ -93,11 +93,13 @@ def _queue_copy(dst: torch.Tensor, src: torch.Tensor) -> None:
 
 
 def upload_staged(parts: Sequence[np.ndarray], device: torch.device) -> List[torch.Tensor]:
-    """Small host arrays (index lists, work-item tables) to the device as ONE copy queued on the CURRENT stream, in
-    order with the launches that read them: the bytes go through page-locked staging memory, so the copy is
-    asynchronous (a copy from pageable memory returns only once it has run, i.e. behind everything the stream already
-    holds) and the host moves on at once.  Returns one device tensor per part (views of one allocation, each starting
-    on a 256-byte boundary, typed like its part)."""
+    """Small host arrays (index lists, work-item tables) to the device as ONE launch on the CURRENT stream, in order
+    with the launches that read them: the bytes are written to page-locked staging memory and a kernel
+    (spice_gather_upload) reads them from there through the memory's device mapping, so the host moves on at once (a
+    copy command, from pageable or page-locked memory alike, keeps the caller until the stream has run that far).
+    Returns one device tensor per part (views of one allocation, each starting on a 256-byte boundary, typed like its
+    part).  More than one staging half (2 MiB) of parts goes as several launches; a single part larger than that as an
+    ordinary copy."""
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("upload_staged needs a HIP device")

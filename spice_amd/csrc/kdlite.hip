@@ -1905,7 +1905,10 @@ static int head_prepare(HeadArgs &ha, const void *low, const int64_t *labels, in
         // arg-max form's registers allow three, but two are faster (29.6 against 30.9 us at [8,21,128,128] -> 512 x 512:
         // fewer rows for the tail to fold), and a second round of workgroups costs either form more than its tail
         // hidden behind the first round saves (loss form: 51.7 / 61.1 / 59.3 us with 2 / 3 / 4 per compute unit)
-        const int reg_limit = 2 * (512 / head2_threads());
+        // (the arg-max form on long inputs - [32,19,256,512] -> 1024 x 2048 is 131,072 tiles - is all interpolation
+        // and no tail to speak of: three per compute unit, 715 against 807 us)
+        const bool long_input = !loss && n * ceil_div(hw, tile_px) >= 16 * 3 * device_cu_count();
+        const int reg_limit = (long_input ? 3 : 2) * (512 / head2_threads());
         if (max_per_cu > reg_limit) max_per_cu = reg_limit;
         if (max_per_cu < 1) max_per_cu = 1;
     } else {

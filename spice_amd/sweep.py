@@ -564,6 +564,12 @@ class SensitivitySweep:
         t0 = time.perf_counter()
         self.join_lanes()
         torch.cuda.synchronize(self.device)
+        # a network whose forward does not stop at its head's convolution (no up-sampling behind it, a head the
+        # library does not take) has no tail to hand to the one-launch kernel: nothing to capture
+        probe = self._forward_to_head(images)
+        if probe is None or probe[1] is None:
+            return info
+        del probe
         for lane in self._lanes:
             lane.fused_head = self.fused_head
             for k in range(1, len(tape)):
@@ -608,7 +614,10 @@ class SensitivitySweep:
             with torch.cuda.stream(stream):
                 self.model.attach_tape(tape.replay(k, given=statics))
                 try:
-                    self._forward_to_head(images)   # once eagerly: whatever the launches set up lazily exists before the capture
+                    warm = self._forward_to_head(images)   # once eagerly: whatever the launches set up lazily exists before the capture
+                    if warm is None or warm[1] is None:
+                        return None   # (the forward does not stop at the head's convolution: nothing to capture)
+                    del warm
                     side.wait_stream(stream)
                     if self._graph_pool is None:
                         # one memory pool for all graphs of a lane: they never run at the same time, and each keeps

@@ -17,9 +17,11 @@ activations of the un-pruned network in front of that block come from the teache
 same sweep), and ONE launch for the head's up-sampling, the mIoU confusion matrix (arg-max
 histogram) and the KD-Lite loss against the un-pruned network's logits.  Weak scaling: every rank
 evaluates K candidates spread evenly over its cost-balanced share; the per-candidate tables are
-combined with one all-reduce inside the timed region.  Set-up outside the timed region: model build,
-the Taylor calibration pass (HIP Taylor reduction) with quota allocation, group magnitude importance
-(HIP), launch plans of the warm-up candidates.  Rank 0 prints ONE JSON line.
+combined with one all-reduce inside the timed region; the timed candidates' launch plans are made
+inside it, each in front of its candidate's launches (uploaded by a launch).  Set-up outside the
+timed region: model build, the Taylor calibration pass (HIP Taylor reduction) with quota allocation,
+group magnitude importance (HIP), launch plans of the warm-up candidates, the un-pruned network's
+forward from every block on as captured HIP graphs (once per geometry).  Rank 0 prints ONE JSON line.
 
     python bench.py --gpus N --strong
 times the WHOLE sweep instead (strong scaling: the 414 candidates are fixed, ranks share them):

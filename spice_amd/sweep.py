@@ -119,6 +119,7 @@ class SensitivitySweep:
         #: the caller captured in an enclosing session() are used either way
         self.graphs_in_run = os.environ.get("SPICE_SWEEP_RUN_GRAPHS", "0") == "1"
         self._graphs: Dict[int, object] = {}   # first unit inside the graph -> _SuffixGraph
+        self._runs_on: Dict[tuple, int] = {}   # batch geometry -> run() calls seen
         self._graphs_for = None                # what they were captured on
         self._graph_pool = None
         self._weights_version = 0
@@ -771,8 +772,16 @@ class SensitivitySweep:
         # front: a look-up synchronises the stream, which is cheap while nothing is queued.
         # (without captured graphs for the unchanged units the host, not the device, sets the pace of the loop: plans
         # made in a row up front then cost less than plans made between the launches)
-        graphs = self.suffix_graphs and (any(l._graphs for l in self._lanes) or
-                                         (self.graphs_in_run and len(mine) >= self.GRAPHS_FROM_CANDIDATES))
+        # Captured graphs for the unchanged units: a single sweep gets their capture time back about evenly, so run()
+        # captures them only on request (graphs_in_run) - or from the SECOND run on a geometry inside a session the
+        # caller holds open (an analysis over several batches: the graphs live until that session ends, and the first
+        # run has shown that more are coming).
+        shape = tuple(images.shape)
+        self._runs_on[shape] = self._runs_on.get(shape, 0) + 1
+        have = any(l._graphs for l in self._lanes)
+        capture = self.suffix_graphs and not have and len(mine) >= self.GRAPHS_FROM_CANDIDATES and (
+            self.graphs_in_run or (self._session_depth > 0 and self._runs_on[shape] >= 2))
+        graphs = self.suffix_graphs and (have or capture)
         if self.plans_up_front or not graphs or self.may_need_solver_lookups(images):
             self.prepare(mine)
             dev_sync()
@@ -797,7 +806,7 @@ class SensitivitySweep:
             del unpruned
             dev_sync()
             ph["teacher_forward_s"], t = time.perf_counter() - t, time.perf_counter()
-            if self.graphs_in_run and len(mine) >= self.GRAPHS_FROM_CANDIDATES:
+            if capture:
                 self.capture_suffix_graphs(images)
                 dev_sync()
                 ph["graph_capture_s"], t = time.perf_counter() - t, time.perf_counter()

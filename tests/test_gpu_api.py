@@ -748,3 +748,32 @@ def test_sweep_plans_made_between_the_launches(dev):
     assert torch.equal(tables[0]["kd"], tables[1]["kd"])
     fp32 = SensitivitySweep(model, 21, ratios=(0.5,), ignored_layers=ignored, autocast_dtype=None)
     assert fp32.may_need_solver_lookups(x)                  # the fp32 forward runs on torch's convolutions
+
+
+def test_sweep_captures_its_graphs_from_the_second_run_of_a_held_session(dev):
+    """An analysis over several batches inside one session: the first run() queues every launch itself, the second
+    one captures the graphs (they live until the session ends) and runs on them; tables equal a sweep that never does."""
+    from spice_amd.sweep import DEFAULT_RATIOS
+    torch.manual_seed(11)
+    model = nets.create_model("DeepLabV3Plus", "resnet50", 21).to(dev).eval()
+    ignored = [m for m in model.segmentation_head.modules() if isinstance(m, nn.Conv2d)]
+    xs = [torch.randn(2, 3, 256, 256, device=dev) for _ in range(2)]
+    labs = [torch.from_numpy(synth.label_map(s, 2, 256, 256, 21, "blocky", ignore_share=0.05)).to(dev) for s in (1, 2)]
+    plain = SensitivitySweep(model, 21, DEFAULT_RATIOS, ignored_layers=ignored)
+    plain.suffix_graphs = False
+    want = [plain.run(x, l) for x, l in zip(xs, labs)]
+    sweep = SensitivitySweep(model, 21, DEFAULT_RATIOS, ignored_layers=ignored)
+    sweep.run(xs[0], labs[0])                       # no session held: nothing captured, however often it runs
+    sweep.run(xs[0], labs[0])
+    assert sweep.graph_launches == 0 and not sweep._graphs
+    sweep._runs_on.clear()
+    with sweep.session():
+        first = sweep.run(xs[0], labs[0])
+        assert sweep.graph_launches == 0 and not sweep._graphs
+        second = sweep.run(xs[1], labs[1])
+        assert sweep.graph_launches > 100 and sweep._graphs
+        assert "graph_capture_s" in sweep.last_share["phases"] and sweep.last_share["phases"]["plans_s"] == 0.0
+    assert not sweep._graphs
+    for got, ref in ((first, want[0]), (second, want[1])):
+        assert torch.equal(got["confusion"], ref["confusion"])
+        assert torch.allclose(got["kd"], ref["kd"], rtol=1e-5, atol=1e-7)

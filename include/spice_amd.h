@@ -421,6 +421,15 @@ int spice_depthwise_conv3x3_dilated(const void *x, const void *weight, int32_t w
                                     int64_t n, int64_t c, int32_t h, int32_t w, int32_t dilation,
                                     void *stream);
 
+/* Depthwise k x k convolution, k = 3 or 5, stride 1 or 2, dilation 1 or 2, padding (k / 2) * dilation, no bias: the
+ * depthwise convolutions of the EfficientNet encoders (pruning/models.py:35-39 with "timm-efficientnet-b3"), which
+ * MIOpen serves image by image with an unfold pass and a matrix product.  x [n, c, h, w] and y [n, c, oh, ow] fp16
+ * contiguous, oh = (h - 1) / stride + 1, ow likewise; weight [c, 1, k, k] fp16 (1) or fp32 (0).  Same arithmetic as
+ * spice_depthwise_conv3x3: the k * k products added to an fp32 sum in tap order, one rounding.  w must be even.
+ * SPICE_ERR_UNSUPPORTED for every other kernel size, stride, dilation or width. */
+int spice_depthwise_conv_f16(const void *x, const void *weight, int32_t weight_dtype, void *y, int64_t n, int64_t c,
+                             int32_t h, int32_t w, int32_t kernel, int32_t stride, int32_t dilation, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * (8) 1x1 stride-1 convolution of fp16 NCHW activations, without bias:
  *   y[n][Cout, HW] = weight[Cout, Cin] @ x[n][Cin, HW]   (fp32 accumulation).

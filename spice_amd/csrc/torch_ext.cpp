@@ -556,6 +556,27 @@ std::tuple<Tensor, Tensor> bn_act_maxpool(const Tensor &x, const Tensor &mean, c
     return std::make_tuple(full, pooled);
 }
 
+Tensor depthwise_conv(const Tensor &x, const Tensor &weight, int64_t stride, int64_t dilation) {
+    check_dev(x, "x", at::kHalf);
+    TORCH_CHECK_TYPE(weight.scalar_type() == at::kHalf || weight.scalar_type() == at::kFloat,
+                     "depthwise_conv: weight dtype ", weight.scalar_type(), " not supported");
+    check_dev(weight, "weight", weight.scalar_type());
+    check_same_device(x, weight, "weight");
+    TORCH_CHECK_VALUE(x.dim() == 4 && weight.dim() == 4 && weight.size(0) == x.size(1) && weight.size(1) == 1 &&
+                          weight.size(2) == weight.size(3),
+                      "depthwise_conv: x must be [N,C,H,W] and weight [C,1,k,k]");
+    TORCH_CHECK_VALUE(stride >= 1 && stride <= 2 && x.size(2) >= 1 && x.size(3) >= 1, "depthwise_conv: stride must be 1 or 2");
+    c10::DeviceGuard guard(x.device());
+    const int64_t oh = (x.size(2) - 1) / stride + 1, ow = (x.size(3) - 1) / stride + 1;
+    Tensor out = at::empty({x.size(0), x.size(1), oh, ow}, x.options());
+    const int32_t wcode = weight.scalar_type() == at::kFloat ? 0 : 1;
+    check_rc(spice_depthwise_conv_f16(x.data_ptr(), weight.data_ptr(), wcode, out.data_ptr(), x.size(0), x.size(1),
+                                      (int32_t)x.size(2), (int32_t)x.size(3), (int32_t)weight.size(2), (int32_t)stride,
+                                      (int32_t)dilation, current_stream(x)),
+             "spice_depthwise_conv_f16");
+    return out;
+}
+
 Tensor depthwise_conv3x3(const Tensor &x, const Tensor &weight, int64_t dilation) {
     check_dev(x, "x", at::kHalf);
     TORCH_CHECK_TYPE(weight.scalar_type() == at::kHalf || weight.scalar_type() == at::kFloat,
@@ -830,6 +851,7 @@ TORCH_LIBRARY(spice, m) {
     m.def("bn_act_maxpool(Tensor x, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, bool relu, "
           "bool want_full) -> (Tensor, Tensor)", &bn_act_maxpool);
     m.def("depthwise_conv3x3(Tensor x, Tensor weight, int dilation) -> Tensor", &depthwise_conv3x3);
+    m.def("depthwise_conv(Tensor x, Tensor weight, int stride, int dilation) -> Tensor", &depthwise_conv);
     m.def("conv1x1_f16(Tensor x, Tensor weight2d, int stride) -> Tensor", &conv1x1_f16);
     m.def("conv7x7_s2(Tensor x, Tensor weight2d) -> Tensor", &conv7x7_s2);
     m.def("conv3x3_bn_act(Tensor x, Tensor weight9, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, "

@@ -8,6 +8,8 @@ from typing import List
 import torch
 import torch.nn as nn
 
+from .layers import DepthwiseConvKxK
+
 
 def _round_channels(ch: float, divisor: int = 8) -> int:
     new = max(divisor, int(ch + divisor / 2) // divisor * divisor)
@@ -32,9 +34,8 @@ class SqueezeExcite(nn.Module):
 class DepthwiseSeparable(nn.Module):
     def __init__(self, in_chs: int, out_chs: int, kernel: int, stride: int, dilation: int = 1):
         super().__init__()
-        pad = (kernel // 2) * dilation
         self.has_skip = stride == 1 and in_chs == out_chs
-        self.conv_dw = nn.Conv2d(in_chs, in_chs, kernel, stride, pad, dilation, groups=in_chs, bias=False)
+        self.conv_dw = DepthwiseConvKxK(in_chs, kernel, stride, dilation)
         self.bn1 = nn.BatchNorm2d(in_chs)
         self.act1 = nn.SiLU(inplace=True)
         self.se = SqueezeExcite(in_chs, max(1, round(in_chs * 0.25)))
@@ -52,12 +53,11 @@ class InvertedResidual(nn.Module):
                  dilation: int = 1):
         super().__init__()
         mid = in_chs * expand
-        pad = (kernel // 2) * dilation
         self.has_skip = stride == 1 and in_chs == out_chs
         self.conv_pw = nn.Conv2d(in_chs, mid, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(mid)
         self.act1 = nn.SiLU(inplace=True)
-        self.conv_dw = nn.Conv2d(mid, mid, kernel, stride, pad, dilation, groups=mid, bias=False)
+        self.conv_dw = DepthwiseConvKxK(mid, kernel, stride, dilation)
         self.bn2 = nn.BatchNorm2d(mid)
         self.act2 = nn.SiLU(inplace=True)
         self.se = SqueezeExcite(mid, max(1, round(in_chs * 0.25)))

@@ -90,6 +90,32 @@ class DepthwiseConv3x3(nn.Conv2d):
         return super().forward(x)
 
 
+class DepthwiseConvKxK(nn.Conv2d):
+    """nn.Conv2d(ch, ch, k, stride, (k // 2) * dilation, dilation, groups=ch, bias=False), k = 3 or 5: the depthwise
+    convolutions of the EfficientNet blocks.  On fp16 activations (autocast) under no_grad on a HIP device, stride 1 or
+    2, dilation 1 or 2 and an even width, the forward is the library's tiled kernel: fp32 sums of the k * k (exact)
+    products in tap order, one rounding - the arithmetic of torch's own depthwise kernel (MIOpen serves most of these
+    calls image by image with an unfold pass and a matrix product).  In every other situation torch's conv2d runs."""
+
+    def __init__(self, channels: int, kernel: int, stride: int = 1, dilation: int = 1):
+        super().__init__(channels, channels, kernel, stride, (kernel // 2) * dilation, dilation, groups=channels, bias=False)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        k, s, d = self.kernel_size[0], self.stride[0], self.dilation[0]
+        pad = (k // 2) * d
+        plain = (self.kernel_size == (k, k) and self.stride == (s, s) and self.dilation == (d, d)
+                 and self.padding == (pad, pad) and self.padding_mode == "zeros" and self._parameters["bias"] is None
+                 and self.groups == self.in_channels == self.out_channels)
+        if (_LIBRARY_FORWARD and not torch.is_grad_enabled() and x.is_cuda and plain
+                and (x.dtype == torch.float16 or torch.is_autocast_enabled("cuda"))):
+            if x.dtype != torch.float16 and torch.get_autocast_dtype("cuda") == torch.float16:
+                x = x.to(torch.float16)   # what autocast does to a convolution's input
+            w = self._parameters["weight"]
+            if ops.depthwise_conv_supported(x, w, s, d):
+                return ops.depthwise_conv(x, w, s, d)
+        return super().forward(x)
+
+
 # fp16 copies of convolution weights, per Parameter object: id -> (weak reference, version, [Cout, Cin * kh * kw] fp16).
 # The same bookkeeping autocast does for the weights it casts: one cast per Parameter and version, dropped
 # with the Parameter.

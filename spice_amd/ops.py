@@ -669,6 +669,23 @@ def depthwise_conv3x3(x: torch.Tensor, weight: torch.Tensor, dilation: int = 1) 
     return spice_ops().depthwise_conv3x3(x, weight, int(dilation))
 
 
+def depthwise_conv_supported(x: torch.Tensor, weight: torch.Tensor, stride: int, dilation: int) -> bool:
+    """Whether depthwise_conv takes this call: contiguous fp16 NCHW of even width, a [C,1,k,k] weight with k = 3 or 5,
+    stride 1 or 2, dilation 1 or 2."""
+    return (x.dim() == 4 and x.dtype == torch.float16 and x.is_contiguous() and x.shape[3] % 2 == 0 and x.shape[2] >= 1
+            and weight.dim() == 4 and weight.shape[0] == x.shape[1] and weight.shape[1] == 1
+            and weight.shape[2] == weight.shape[3] and weight.shape[2] in (3, 5) and weight.is_contiguous()
+            and weight.dtype in (torch.float16, torch.float32) and stride in (1, 2) and dilation in (1, 2)
+            and x.shape[0] * x.shape[1] < (1 << 24))
+
+
+def depthwise_conv(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, dilation: int = 1) -> torch.Tensor:
+    """conv2d(x, weight, stride=stride, padding=(k // 2) * dilation, dilation=dilation, groups=C) for fp16 x and a
+    k x k weight, k = 3 or 5: fp32 sums of the k * k products in tap order, one rounding (what torch's own depthwise
+    kernel computes)."""
+    return spice_ops().depthwise_conv(x, weight, int(stride), int(dilation))
+
+
 _conv1x1_fn = None
 
 # Measurement hook (bench.py): a list to which every convolution call below appends

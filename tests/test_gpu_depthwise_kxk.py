@@ -1,0 +1,104 @@
+"""The tiled depthwise k x k kernel (EfficientNet blocks): exact on integer data, fp64 sums on random data, the
+module against torch's convolution, what the entry point declines."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from spice_amd import _native as nat
+from spice_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+CASES = [(2, 5, 16, 16), (1, 3, 34, 70), (2, 4, 64, 64), (1, 2, 130, 256), (1, 7, 9, 18), (3, 6, 33, 32), (1, 2, 2, 2)]
+
+
+@pytest.mark.parametrize("k", [3, 5])
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("dilation", [1, 2])
+@pytest.mark.parametrize("shape", CASES)
+def test_depthwise_kxk_exact_on_integer_data(dev, k, stride, dilation, shape):
+    """Small integers: every product and every partial sum is exact in fp32 and in fp16, whatever the order - the
+    kernel must give torch's CPU convolution bit for bit, image edges, tile edges and odd output widths included;
+    fp32 and fp16 weights alike."""
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(k * 100 + stride * 10 + dilation + h)
+    x = torch.randint(-4, 5, shape, generator=g).float()
+    wt = torch.randint(-3, 4, (c, 1, k, k), generator=g).float()
+    want = F.conv2d(x, wt, None, stride, (k // 2) * dilation, dilation, groups=c).half()
+    assert ops.depthwise_conv_supported(x.half().to(dev), wt.to(dev), stride, dilation)
+    for wdev in (wt.to(dev), wt.half().to(dev)):
+        got = ops.depthwise_conv(x.half().to(dev), wdev, stride, dilation)
+        assert got.dtype == torch.float16 and got.shape == want.shape
+        assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("k,stride,dilation,shape", [(3, 2, 1, (8, 144, 64, 64)), (5, 2, 1, (4, 192, 64, 64)),
+                                                      (5, 1, 1, (4, 288, 32, 32)), (5, 1, 2, (2, 816, 32, 32)),
+                                                      (3, 1, 2, (2, 1392, 32, 32)), (3, 1, 1, (2, 40, 128, 128))])
+def test_depthwise_kxk_random_data_against_fp64_and_torch(dev, k, stride, dilation, shape):
+    """Random data at the block shapes of the B3 encoder: within one fp16 step of the fp64 sums, and of torch's own
+    device convolution."""
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(k + stride + dilation)
+    x = torch.randn(shape, generator=g).half()
+    wt = (torch.randn(c, 1, k, k, generator=g) / k).half()
+    exact = F.conv2d(x.double(), wt.double(), None, stride, (k // 2) * dilation, dilation, groups=c)
+    got = ops.depthwise_conv(x.to(dev), wt.to(dev), stride, dilation)
+    step = 1e-3 * max(1.0, float(exact.abs().max()))
+    assert float((got.cpu().double() - exact).abs().max()) <= step
+    there = F.conv2d(x.to(dev), wt.to(dev), None, stride, (k // 2) * dilation, dilation, groups=c)
+    assert float((got.float() - there.float()).abs().max()) <= 2 * step
+
+
+def test_efficientnet_blocks_take_the_library_depthwise_kernel(dev):
+    """The encoder under fp16 autocast with and without the library forward: every feature map within fp16 rounding
+    of torch's modules; the depthwise module falls back to torch's convolution where the kernel does not apply."""
+    from spice_amd.nets import layers
+    from spice_amd.nets.efficientnet import EfficientNetB3Encoder
+    torch.manual_seed(5)
+    enc = EfficientNetB3Encoder(output_stride=16).to(dev).eval()
+    assert sum(isinstance(m, layers.DepthwiseConvKxK) for m in enc.modules()) == 26
+    x = torch.randn(2, 3, 128, 128, device=dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        lib = enc(x)
+        layers.set_library_forward(False)
+        try:
+            ref = enc(x)
+        finally:
+            layers.set_library_forward(True)
+    for a, b in zip(lib[1:], ref[1:]):
+        assert a.shape == b.shape and a.dtype == b.dtype
+        scale = max(1.0, float(b.float().abs().max()))
+        assert float((a.float() - b.float()).abs().max()) <= 2e-2 * scale
+    dw = layers.DepthwiseConvKxK(6, 5, stride=2).to(dev)
+    odd = torch.randn(1, 6, 9, 9, device=dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        y = dw(odd)    # odd width: torch's convolution
+    assert y.shape == (1, 6, 5, 5)
+    with torch.autocast("cuda", dtype=torch.float16):
+        assert dw(torch.randn(1, 6, 8, 8, device=dev)).requires_grad   # gradients wanted: torch's convolution
+
+
+def test_depthwise_kxk_entry_point_declines(dev):
+    L = nat.lib()
+    x = torch.zeros(1, 2, 8, 8, dtype=torch.float16, device=dev)
+    w = torch.zeros(2, 1, 7, 7, dtype=torch.float16, device=dev)
+    y = torch.zeros(1, 2, 8, 8, dtype=torch.float16, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def call(k, s, d, wd=8):
+        return L.spice_depthwise_conv_f16(x.data_ptr(), w.data_ptr(), 1, y.data_ptr(), 1, 2, 8, wd, k, s, d, st)
+    assert call(7, 1, 1) == nat.ERR_UNSUPPORTED and call(3, 3, 1) == nat.ERR_UNSUPPORTED and call(3, 1, 4) == nat.ERR_UNSUPPORTED
+    assert call(3, 1, 1, wd=7) == nat.ERR_UNSUPPORTED
+    assert call(3, 1, 1) == 0
+    assert not ops.depthwise_conv_supported(x[:, :, :, :7].contiguous(), w[:, :, :3, :3].contiguous(), 1, 1)
+    with pytest.raises(RuntimeError):
+        ops.depthwise_conv(x, w, 1, 1)

@@ -430,6 +430,16 @@ int spice_depthwise_conv3x3_dilated(const void *x, const void *weight, int32_t w
 int spice_depthwise_conv_f16(const void *x, const void *weight, int32_t weight_dtype, void *y, int64_t n, int64_t c,
                              int32_t h, int32_t w, int32_t kernel, int32_t stride, int32_t dilation, void *stream);
 
+/* Squeeze-and-excite of the EfficientNet blocks, fp16 NCHW, inference: y = x * sigmoid(W2 silu(W1 mean(x) + b1) + b2),
+ * mean over each plane; x, y [n, c, hw] fp16 contiguous, w1 [r, c], b1 [r], w2 [c, r], b2 [c] fp32 (rounded to fp16
+ * where used, as autocast casts them).  Replaces torch's reduction, two 1x1 convolutions through MIOpen and four
+ * element-wise launches with three launches; every intermediate is rounded to fp16 where torch's modules would store
+ * it.  workspace: spice_squeeze_excite_workspace_bytes(n, c) bytes, 256-byte aligned.  c <= 4096, r <= 1024. */
+size_t spice_squeeze_excite_workspace_bytes(int64_t n, int64_t c);
+int spice_squeeze_excite_f16(const void *x, void *y, int64_t n, int64_t c, int64_t hw, const float *w1, const float *b1,
+                             int64_t r, const float *w2, const float *b2, void *workspace, size_t workspace_bytes,
+                             void *stream);
+
 /* ------------------------------------------------------------------------- *
  * (8) 1x1 stride-1 convolution of fp16 NCHW activations, without bias:
  *   y[n][Cout, HW] = weight[Cout, Cin] @ x[n][Cin, HW]   (fp32 accumulation).

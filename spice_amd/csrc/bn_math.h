@@ -5,6 +5,10 @@
 //         rounded to the tensor's dtype (for fp16: to nearest even, as a separate step)
 //   add:  the two rounded operands added in fp32, rounded again
 //   relu: max(v, 0), NaN kept
+//   silu (tail code 2, the EfficientNet blocks): v / (1 + exp(-v)) in fp32 on the rounded value, rounded again
+//         (torch's kernel for the dtype does the same; the exponential and the reciprocal here are the hardware's
+//         1-ulp instructions, so a result can differ from torch's in its last fp32 bits and - rarely - by one step of
+//         the storage type)
 #pragma once
 
 #include "common.h"
@@ -36,6 +40,13 @@ __device__ __forceinline__ float round_trip<_Float16>(float v) {
     return static_cast<float>(static_cast<_Float16>(v));
 }
 
+__device__ __forceinline__ float silu_f32(float v) {
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v));
+}
+
+// Tail codes of the entry points' `relu` argument: 0 none, 1 ReLU, 2 SiLU (any other non-zero value: ReLU).
+__host__ __device__ __forceinline__ int tail_code(int relu) { return relu == 2 ? 2 : (relu ? 1 : 0); }
+
 // relu?( bn_p(x) [+ r | + bn_q(r)] ) for one element; x and r are values of the storage type T
 template <typename T, bool HAS_RES, bool RES_BN>
 __device__ __forceinline__ float bn_tail(float x, float r, const BnChannel &p, const BnChannel &q, int relu) {
@@ -46,7 +57,8 @@ __device__ __forceinline__ float bn_tail(float x, float r, const BnChannel &p, c
             r = round_trip<T>(__builtin_fmaf(q.weight, (r - q.mean) * q.inv, q.bias));
         v = round_trip<T>(v + r);
     }
-    if (relu) v = v != v ? v : fmaxf(v, 0.0f);
+    if (relu == 1) v = v != v ? v : fmaxf(v, 0.0f);
+    else if (relu == 2) v = silu_f32(v);
     return v;
 }
 

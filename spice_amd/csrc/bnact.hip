@@ -152,7 +152,7 @@ static int bn_act_launch(const void *x, const void *residual, void *y, int32_t d
     a.n_vec = static_cast<unsigned>(wide ? total / vec : total);
     a.hw = static_cast<unsigned>(hw);
     a.c = static_cast<unsigned>(c);
-    a.relu = relu ? 1 : 0;
+    a.relu = tail_code(relu);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == 1) return wide ? launch_bn<_Float16, 8>(a, st) : launch_bn<_Float16, 1>(a, st);
     return wide ? launch_bn<float, 4>(a, st) : launch_bn<float, 1>(a, st);

@@ -116,7 +116,11 @@ __device__ __forceinline__ half2_t bn_tail_pair(half2_t x, half2_t r, const BnCh
         asm volatile("" : "+v"(sum));
         v = half2_t{static_cast<_Float16>(sum[0]), static_cast<_Float16>(sum[1])};
     }
-    if (relu) v = __builtin_elementwise_maximum(v, half2_t{0, 0});   // NaN-propagating maximum
+    if (relu == 1) v = __builtin_elementwise_maximum(v, half2_t{0, 0});   // NaN-propagating maximum
+    else if (relu == 2) {   // SiLU on the rounded halves, in fp32, rounded again (bn_math.h)
+        const float2_t f = {silu_f32(static_cast<float>(v[0])), silu_f32(static_cast<float>(v[1]))};
+        v = half2_t{static_cast<_Float16>(f[0]), static_cast<_Float16>(f[1])};
+    }
     return v;
 }
 
@@ -1032,7 +1036,7 @@ static int conv1x1_launch(const void *x, const void *weight, void *y, int64_t n,
     a.tiles_m = static_cast<int>(tiles_m_used);
     a.tiles_n = static_cast<int>(tiles_n);
     a.total_tiles = static_cast<unsigned>(tiles_m_used * tiles_n * n);
-    a.relu = relu ? 1 : 0;
+    a.relu = tail_code(relu);
     a.chunked = (c3 && c3_stride == 1 && cin % kMmBK == 0 && mm_chunked_knob() != 0) ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (c7) {
@@ -1163,7 +1167,7 @@ static int conv3x3_halo_launch(const void *x, const void *weight9, void *y, int6
     a.weight = bn_weight;
     a.bias = bn_bias;
     a.eps = eps;
-    a.relu = relu ? 1 : 0;
+    a.relu = tail_code(relu);
     a.M = (int)cout;
     a.cin = (int)cin;
     a.h = h;

@@ -1,0 +1,200 @@
+// Squeeze-and-excite of the EfficientNet blocks (the models of pruning/models.py:35-39 built on
+// "timm-efficientnet-b3"), fp16 NCHW, inference:
+//     s = mean over the plane of x          [N, C]
+//     h = silu(W1 s + b1)                   [N, R]
+//     g = sigmoid(W2 h + b2)                [N, C]
+//     y = x * g
+// torch runs this as a reduction, two 1x1 convolutions on 1 x 1 planes through MIOpen (whose solver look-up a sweep
+// candidate with a new channel count triggers), three element-wise launches and the product: eight-odd launches per
+// block, 26 blocks per forward.  Here it is three: the plane means (a wave per plane), the two small products with
+// their activations (a workgroup per image), the product with x.  Every intermediate is rounded to fp16 where torch's
+// modules would have stored it under fp16 autocast (the mean, each convolution's result, each activation), sums in
+// fp32: within a few fp16 steps of torch's gate, which multiplies x.
+#include "common.h"
+#include "bn_math.h"
+
+#include <hip/hip_fp16.h>
+
+namespace spice {
+
+constexpr int kSeThreads = 256;
+constexpr int kSeMaxChannels = 4096;   // the gate kernel holds an image's means in LDS
+
+typedef _Float16 se_f16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float se_round_half(float v) {
+    asm volatile("" : "+v"(v));
+    return static_cast<float>(static_cast<_Float16>(v));
+}
+
+// mean[plane] = mean of x[plane, :], a wave per plane, fp32 sum, rounded to fp16 (as torch's mean of a half tensor)
+__global__ __launch_bounds__(kSeThreads) void se_mean_kernel(const _Float16 *__restrict__ x, float *__restrict__ mean,
+                                                             int planes, int hw) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int plane = blockIdx.x * (kSeThreads / 64) + wave;
+    if (plane >= planes) return;
+    const _Float16 *src = x + static_cast<int64_t>(plane) * hw;
+    float sum = 0.0f;
+    if ((hw & 7) == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+        const se_f16x8_t *v = reinterpret_cast<const se_f16x8_t *>(src);
+        for (int i = lane; i < (hw >> 3); i += 64) {
+            const se_f16x8_t p = v[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += static_cast<float>(p[e]);
+        }
+    } else {
+        for (int i = lane; i < hw; i += 64) sum += static_cast<float>(src[i]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) mean[plane] = se_round_half(sum / static_cast<float>(hw));
+}
+
+// The same with a workgroup per plane, for planes long enough to keep 256 lanes busy (a wave per plane leaves a
+// [8,40,256,256] tensor to 320 waves).
+__global__ __launch_bounds__(kSeThreads) void se_mean_block_kernel(const _Float16 *__restrict__ x, float *__restrict__ mean,
+                                                                   int hw) {
+    __shared__ float part[kSeThreads / 64];
+    const int plane = blockIdx.x, tid = threadIdx.x;
+    const _Float16 *src = x + static_cast<int64_t>(plane) * hw;
+    float sum = 0.0f;
+    if ((hw & 7) == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+        const se_f16x8_t *v = reinterpret_cast<const se_f16x8_t *>(src);
+        for (int i = tid; i < (hw >> 3); i += kSeThreads) {
+            const se_f16x8_t p = v[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += static_cast<float>(p[e]);
+        }
+    } else {
+        for (int i = tid; i < hw; i += kSeThreads) sum += static_cast<float>(src[i]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((tid & 63) == 0) part[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        float total = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kSeThreads / 64; ++k) total += part[k];
+        mean[plane] = se_round_half(total / static_cast<float>(hw));
+    }
+}
+
+// gate[n, i0 .. i0 + 255] from mean[n, :]: an image's channels in slabs of 256, a workgroup per slab (each computes
+// the R hidden values itself: R * C multiply-adds, less than a launch of their own would cost).  Eight hidden values
+// at a time with every lane's loads of the eight weight rows in flight together: the sums are short and the kernel
+// is all latency otherwise.
+__global__ __launch_bounds__(kSeThreads) void se_gate_kernel(const float *__restrict__ mean, const float *__restrict__ w1,
+                                                             const float *__restrict__ b1, const float *__restrict__ w2,
+                                                             const float *__restrict__ b2, _Float16 *__restrict__ gate,
+                                                             int c, int r, int slabs) {
+    __shared__ float s_mean[kSeMaxChannels];
+    __shared__ float s_hidden[kSeMaxChannels / 4];
+    __shared__ float s_part[kSeThreads / 64][8];
+    const int n = blockIdx.x / slabs, slab = blockIdx.x - n * slabs;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < c; i += kSeThreads) s_mean[i] = mean[static_cast<int64_t>(n) * c + i];
+    __syncthreads();
+    // hidden = silu(W1 mean + b1), weights rounded to fp16 as autocast casts them
+    for (int j0 = 0; j0 < r; j0 += 8) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < c; i += kSeThreads) {
+            const float m = s_mean[i];
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = j0 + u < r ? w1[static_cast<int64_t>(j0 + u) * c + i] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = __builtin_fmaf(se_round_half(wv[u]), m, acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc[u] += __shfl_xor(acc[u], off);
+            if (lane == 0) s_part[wave][u] = acc[u];
+        }
+        __syncthreads();
+        if (tid < 8 && j0 + tid < r) {
+            float total = 0.0f;
+#pragma unroll
+            for (int k = 0; k < kSeThreads / 64; ++k) total += s_part[k][tid];
+            const float pre = se_round_half(total + se_round_half(b1[j0 + tid]));   // the convolution's fp16 result
+            s_hidden[j0 + tid] = se_round_half(silu_f32(pre));
+        }
+        __syncthreads();
+    }
+    // gate = sigmoid(W2 hidden + b2): a lane per channel of the slab
+    const int i = slab * kSeThreads + tid;
+    if (i >= c) return;
+    const float *row = w2 + static_cast<int64_t>(i) * r;
+    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+    int j = 0;
+    for (; j + 4 <= r; j += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc4[u] = __builtin_fmaf(se_round_half(row[j + u]), s_hidden[j + u], acc4[u]);
+    }
+    for (; j < r; ++j) acc4[0] = __builtin_fmaf(se_round_half(row[j]), s_hidden[j], acc4[0]);
+    const float pre = se_round_half((acc4[0] + acc4[1]) + (acc4[2] + acc4[3]) + se_round_half(b2[i]));
+    const float g = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * pre));
+    gate[static_cast<int64_t>(n) * c + i] = static_cast<_Float16>(g);
+}
+
+// y[plane, :] = x[plane, :] * gate[plane]
+__global__ __launch_bounds__(kSeThreads) void se_scale_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ gate,
+                                                              _Float16 *__restrict__ y, int64_t total, int hw, int vec) {
+    const int64_t step = static_cast<int64_t>(gridDim.x) * kSeThreads;
+    if (vec) {
+        const se_f16x8_t *xv = reinterpret_cast<const se_f16x8_t *>(x);
+        se_f16x8_t *yv = reinterpret_cast<se_f16x8_t *>(y);
+        for (int64_t i = static_cast<int64_t>(blockIdx.x) * kSeThreads + threadIdx.x; i < (total >> 3); i += step) {
+            const float g = static_cast<float>(gate[(i << 3) / hw]);   // hw % 8 == 0: a vector lies inside one plane
+            const se_f16x8_t p = xv[i];
+            se_f16x8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = static_cast<_Float16>(static_cast<float>(p[e]) * g);
+            yv[i] = o;
+        }
+    } else {
+        for (int64_t i = static_cast<int64_t>(blockIdx.x) * kSeThreads + threadIdx.x; i < total; i += step)
+            y[i] = static_cast<_Float16>(static_cast<float>(x[i]) * static_cast<float>(gate[i / hw]));
+    }
+}
+
+}  // namespace spice
+
+extern "C" size_t spice_squeeze_excite_workspace_bytes(int64_t n, int64_t c) {
+    if (n < 0 || c < 0) return 0;
+    return static_cast<size_t>(n * c) * 4 + static_cast<size_t>(n * c) * 2 + 256;   // means (fp32), gate (fp16)
+}
+
+extern "C" int spice_squeeze_excite_f16(const void *x, void *y, int64_t n, int64_t c, int64_t hw, const float *w1,
+                                        const float *b1, int64_t r, const float *w2, const float *b2, void *workspace,
+                                        size_t workspace_bytes, void *stream) {
+    using namespace spice;
+    if (n < 0 || c <= 0 || hw <= 0 || r <= 0) return SPICE_ERR_ARG;
+    if (n == 0) return SPICE_OK;
+    if (!x || !y || !w1 || !b1 || !w2 || !b2 || !workspace) return SPICE_ERR_ARG;
+    if (c > kSeMaxChannels || r > kSeMaxChannels / 4 || hw > INT32_MAX || n * c > INT32_MAX) return SPICE_ERR_UNSUPPORTED;
+    if (workspace_bytes < spice_squeeze_excite_workspace_bytes(n, c)) return SPICE_ERR_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0) return SPICE_ERR_ARG;
+    float *mean = static_cast<float *>(workspace);
+    _Float16 *gate = reinterpret_cast<_Float16 *>(static_cast<char *>(workspace) + ((static_cast<size_t>(n * c) * 4 + 15) & ~size_t{15}));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int planes = static_cast<int>(n * c);
+    const _Float16 *xh = static_cast<const _Float16 *>(x);
+    if (hw >= 4096)
+        hipLaunchKernelGGL(se_mean_block_kernel, dim3(planes), dim3(kSeThreads), 0, st, xh, mean, static_cast<int>(hw));
+    else
+        hipLaunchKernelGGL(se_mean_kernel, dim3((planes + 3) / 4), dim3(kSeThreads), 0, st, xh, mean, planes, static_cast<int>(hw));
+    const int slabs = static_cast<int>((c + kSeThreads - 1) / kSeThreads);
+    hipLaunchKernelGGL(se_gate_kernel, dim3(static_cast<unsigned>(n * slabs)), dim3(kSeThreads), 0, st, mean, w1, b1, w2, b2,
+                       gate, static_cast<int>(c), static_cast<int>(r), slabs);
+    const int64_t total = n * c * hw;
+    const int vec = ((hw & 7) == 0 && aligned16(x) && aligned16(y)) ? 1 : 0;
+    const int64_t work = vec ? (total >> 3) : total;
+    int64_t blocks = (work + kSeThreads - 1) / kSeThreads;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(se_scale_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kSeThreads), 0, st, xh, gate,
+                       static_cast<_Float16 *>(y), total, static_cast<int>(hw), vec);
+    SPICE_LAUNCH_CHECK();
+    return SPICE_OK;
+}

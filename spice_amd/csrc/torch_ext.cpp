@@ -479,7 +479,8 @@ Tensor upsample_bilinear(const Tensor &x, int64_t out_h, int64_t out_w, bool ali
 }
 
 Tensor bn_act(const Tensor &x, const Tensor &mean, const Tensor &var, const Tensor &weight, const Tensor &bias,
-              double eps, const c10::optional<Tensor> &residual, bool relu) {
+              double eps, const c10::optional<Tensor> &residual, bool relu, int64_t act) {
+    const int32_t tail = act == 2 ? 2 : (relu || act == 1 ? 1 : 0);   // 0 none, 1 ReLU, 2 SiLU
     const int32_t code = act_code(x, "bn_act");
     TORCH_CHECK(x.is_cuda(), "x is on ", x.device(),
                 "; the MI355X path has no CPU implementation (move the tensor to a HIP device)");
@@ -501,7 +502,7 @@ Tensor bn_act(const Tensor &x, const Tensor &mean, const Tensor &var, const Tens
     Tensor out = at::empty_like(x);
     check_rc(spice_bn_act(x.data_ptr(), res, out.data_ptr(), code, mean.data_ptr<float>(), var.data_ptr<float>(),
                           weight.data_ptr<float>(), bias.data_ptr<float>(), (float)eps, x.size(0), c,
-                          x.size(2) * x.size(3), relu ? 1 : 0, current_stream(x)),
+                          x.size(2) * x.size(3), tail, current_stream(x)),
              "spice_bn_act");
     return out;
 }
@@ -574,6 +575,27 @@ Tensor depthwise_conv(const Tensor &x, const Tensor &weight, int64_t stride, int
                                       (int32_t)x.size(2), (int32_t)x.size(3), (int32_t)weight.size(2), (int32_t)stride,
                                       (int32_t)dilation, current_stream(x)),
              "spice_depthwise_conv_f16");
+    return out;
+}
+
+Tensor squeeze_excite(const Tensor &x, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2) {
+    check_dev(x, "x", at::kHalf);
+    TORCH_CHECK_VALUE(x.dim() == 4, "squeeze_excite: x must be [N,C,H,W]");
+    const int64_t n = x.size(0), c = x.size(1), hw = x.size(2) * x.size(3), r = b1.numel();
+    for (const Tensor *t : {&w1, &b1, &w2, &b2}) {
+        check_dev(*t, "squeeze_excite parameter", at::kFloat);
+        check_same_device(x, *t, "squeeze_excite parameter");
+    }
+    TORCH_CHECK_VALUE(r >= 1 && w1.numel() == r * c && w2.numel() == c * r && b2.numel() == c,
+                      "squeeze_excite: w1 [R,C], b1 [R], w2 [C,R], b2 [C] for x with C channels");
+    c10::DeviceGuard guard(x.device());
+    Tensor out = at::empty_like(x);
+    if (x.numel() == 0) return out;
+    const size_t need = spice_squeeze_excite_workspace_bytes(n, c);
+    Tensor ws = at::empty({(int64_t)need}, x.options().dtype(at::kByte));
+    check_rc(spice_squeeze_excite_f16(x.data_ptr(), out.data_ptr(), n, c, hw, w1.data_ptr<float>(), b1.data_ptr<float>(), r,
+                                      w2.data_ptr<float>(), b2.data_ptr<float>(), ws.data_ptr(), need, current_stream(x)),
+             "spice_squeeze_excite_f16");
     return out;
 }
 
@@ -664,7 +686,8 @@ Tensor conv1x1_bn_act(const Tensor &x, const Tensor &weight2d, const Tensor &mea
                       const c10::optional<Tensor> &r_weight, const c10::optional<Tensor> &r_bias, double r_eps, bool relu,
                       int64_t route, const c10::optional<Tensor> &out_opt, const c10::optional<Tensor> &p_mean,
                       const c10::optional<Tensor> &p_var, const c10::optional<Tensor> &p_weight,
-                      const c10::optional<Tensor> &p_bias, double p_eps, bool p_relu) {
+                      const c10::optional<Tensor> &p_bias, double p_eps, bool p_relu, int64_t act) {
+    const int32_t tail = act == 2 ? 2 : (relu || act == 1 ? 1 : 0);   // 0 none, 1 ReLU, 2 SiLU
     TORCH_CHECK_VALUE(route >= 0 && route <= 2, "conv1x1_bn_act: route must be 0 (choose), 1 (one launch) or 2 (two launches)");
     TORCH_CHECK_TYPE(x.scalar_type() == at::kHalf && weight2d.scalar_type() == at::kHalf,
                      "conv1x1_bn_act: x and weight must be fp16");
@@ -724,7 +747,7 @@ Tensor conv1x1_bn_act(const Tensor &x, const Tensor &weight2d, const Tensor &mea
                               : spice_conv1x1_bn_act_f16(x.data_ptr(), weight2d.data_ptr(), out.data_ptr(), n, cin, h * w, c,
                                                          mean.data_ptr<float>(), var.data_ptr<float>(),
                                                          weight.data_ptr<float>(), bias.data_ptr<float>(), (float)eps, res, rm,
-                                                         rv, rw, rb, (float)r_eps, relu ? 1 : 0, image_stride, pm, pv, pw, pb,
+                                                         rv, rw, rb, (float)r_eps, tail, image_stride, pm, pv, pw, pb,
                                                          (float)p_eps, p_relu ? 1 : 0, current_stream(x));
         if (rc != SPICE_ERR_UNSUPPORTED || route == 1) {
             check_rc(rc, "spice_conv1x1_bn_act_f16");
@@ -745,11 +768,11 @@ Tensor conv1x1_bn_act(const Tensor &x, const Tensor &weight2d, const Tensor &mea
     if (rm != nullptr) {
         rc = spice_bn_act_dual(t.data_ptr(), res, t.data_ptr(), 1, mean.data_ptr<float>(), var.data_ptr<float>(),
                                weight.data_ptr<float>(), bias.data_ptr<float>(), (float)eps, rm, rv, rw, rb, (float)r_eps,
-                               t.size(0), c, t.size(2) * t.size(3), relu ? 1 : 0, current_stream(t));
+                               t.size(0), c, t.size(2) * t.size(3), tail, current_stream(t));
     } else {
         rc = spice_bn_act(t.data_ptr(), res, t.data_ptr(), 1, mean.data_ptr<float>(), var.data_ptr<float>(),
                           weight.data_ptr<float>(), bias.data_ptr<float>(), (float)eps, t.size(0), c, t.size(2) * t.size(3),
-                          relu ? 1 : 0, current_stream(t));
+                          tail, current_stream(t));
     }
     check_rc(rc, "spice_bn_act (behind conv1x1)");
     if (out_opt.has_value()) {   // the two-launch route writes a dense tensor: one more pass into the slice
@@ -785,7 +808,7 @@ Tensor conv7x7_s2(const Tensor &x, const Tensor &weight2d) {
 }
 
 Tensor conv3x3_bn_act(const Tensor &x, const Tensor &weight9, const Tensor &mean, const Tensor &var, const Tensor &weight,
-                      const Tensor &bias, double eps, bool relu, int64_t stride, int64_t dilation) {
+                      const Tensor &bias, double eps, bool relu, int64_t stride, int64_t dilation, int64_t act) {
     TORCH_CHECK_TYPE(x.scalar_type() == at::kHalf && weight9.scalar_type() == at::kHalf,
                      "conv3x3_bn_act: x and weight must be fp16");
     TORCH_CHECK(x.is_cuda(), "x is on ", x.device(),
@@ -805,8 +828,8 @@ Tensor conv3x3_bn_act(const Tensor &x, const Tensor &weight9, const Tensor &mean
     if (out.numel() != 0)
         check_rc(spice_conv3x3_bn_act_f16(x.data_ptr(), weight9.data_ptr(), out.data_ptr(), n, cin, (int32_t)h, (int32_t)w, c,
                                           (int32_t)stride, (int32_t)dilation, mean.data_ptr<float>(), var.data_ptr<float>(),
-                                          weight.data_ptr<float>(), bias.data_ptr<float>(), (float)eps, relu ? 1 : 0,
-                                          current_stream(x)),
+                                          weight.data_ptr<float>(), bias.data_ptr<float>(), (float)eps,
+                                          act == 2 ? 2 : (relu || act == 1 ? 1 : 0), current_stream(x)),
                  "spice_conv3x3_bn_act_f16");
     return out;
 }
@@ -845,19 +868,20 @@ TORCH_LIBRARY(spice, m) {
     m.def("upsample_bilinear(Tensor x, int out_h, int out_w, bool align_corners, float scale_h, float scale_w, "
           "int out_dtype, Tensor(a!)? out) -> Tensor(a!)", &upsample_bilinear);
     m.def("bn_act(Tensor x, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, Tensor? residual, "
-          "bool relu) -> Tensor", &bn_act);
+          "bool relu, int act=0) -> Tensor", &bn_act);
     m.def("bn_act_dual(Tensor x, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, Tensor residual, "
           "Tensor r_mean, Tensor r_var, Tensor r_weight, Tensor r_bias, float r_eps, bool relu) -> Tensor", &bn_act_dual);
     m.def("bn_act_maxpool(Tensor x, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, bool relu, "
           "bool want_full) -> (Tensor, Tensor)", &bn_act_maxpool);
     m.def("depthwise_conv3x3(Tensor x, Tensor weight, int dilation) -> Tensor", &depthwise_conv3x3);
     m.def("depthwise_conv(Tensor x, Tensor weight, int stride, int dilation) -> Tensor", &depthwise_conv);
+    m.def("squeeze_excite(Tensor x, Tensor w1, Tensor b1, Tensor w2, Tensor b2) -> Tensor", &squeeze_excite);
     m.def("conv1x1_f16(Tensor x, Tensor weight2d, int stride) -> Tensor", &conv1x1_f16);
     m.def("conv7x7_s2(Tensor x, Tensor weight2d) -> Tensor", &conv7x7_s2);
     m.def("conv3x3_bn_act(Tensor x, Tensor weight9, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, "
-          "bool relu, int stride, int dilation) -> Tensor", &conv3x3_bn_act);
+          "bool relu, int stride, int dilation, int act=0) -> Tensor", &conv3x3_bn_act);
     m.def("conv1x1_bn_act(Tensor x, Tensor weight2d, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, "
           "Tensor? residual, Tensor? r_mean, Tensor? r_var, Tensor? r_weight, Tensor? r_bias, float r_eps, bool relu, "
           "int route, Tensor(a!)? out, Tensor? p_mean, Tensor? p_var, Tensor? p_weight, Tensor? p_bias, float p_eps, "
-          "bool p_relu) -> Tensor(a!)", &conv1x1_bn_act);
+          "bool p_relu, int act=0) -> Tensor(a!)", &conv1x1_bn_act);
 }

@@ -8,7 +8,9 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .layers import DepthwiseConvKxK
+from .. import ops
+from . import layers
+from .layers import BatchNormAct2d, Conv1x1, DepthwiseConvKxK, conv1x1_bn, conv3x3_bn
 
 
 def _round_channels(ch: float, divisor: int = 8) -> int:
@@ -25,7 +27,24 @@ class SqueezeExcite(nn.Module):
         self.act1 = nn.SiLU(inplace=True)
         self.conv_expand = nn.Conv2d(reduced, channels, 1)
 
+    def served_by_library(self, x_dtype: torch.dtype) -> bool:
+        """Whether forward() on fp16 activations is the library's three launches (no MIOpen call, no solver lookup for
+        the two 1x1 convolutions)."""
+        a, b = self.conv_reduce, self.conv_expand
+        return (layers.library_forward() and type(a) is nn.Conv2d and type(b) is nn.Conv2d
+                and a.kernel_size == (1, 1) and b.kernel_size == (1, 1) and a.stride == (1, 1) and b.stride == (1, 1)
+                and a.padding == (0, 0) and b.padding == (0, 0) and a.groups == 1 and b.groups == 1
+                and a.bias is not None and b.bias is not None and a.weight.dtype == torch.float32
+                and a.in_channels == b.out_channels and a.out_channels == b.in_channels
+                and a.in_channels <= 4096 and a.out_channels <= 1024 and type(self.act1) is nn.SiLU
+                and x_dtype == torch.float16
+                and not (layers._hooked(a) or layers._hooked(b) or layers._hooked(self.act1)))
+
     def forward(self, x):
+        if (not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.is_contiguous()
+                and self.served_by_library(x.dtype)):
+            return ops.squeeze_excite(x, self.conv_reduce.weight, self.conv_reduce.bias, self.conv_expand.weight,
+                                      self.conv_expand.bias)
         s = x.mean((2, 3), keepdim=True)
         s = self.conv_expand(self.act1(self.conv_reduce(s)))
         return x * torch.sigmoid(s)
@@ -36,16 +55,16 @@ class DepthwiseSeparable(nn.Module):
         super().__init__()
         self.has_skip = stride == 1 and in_chs == out_chs
         self.conv_dw = DepthwiseConvKxK(in_chs, kernel, stride, dilation)
-        self.bn1 = nn.BatchNorm2d(in_chs)
-        self.act1 = nn.SiLU(inplace=True)
+        self.bn1 = BatchNormAct2d(in_chs, silu=True)   # batch-norm + SiLU: one launch on the inference path
+        self.act1 = nn.Identity()
         self.se = SqueezeExcite(in_chs, max(1, round(in_chs * 0.25)))
-        self.conv_pw = nn.Conv2d(in_chs, out_chs, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(out_chs)
+        self.conv_pw = Conv1x1(in_chs, out_chs)
+        self.bn2 = BatchNormAct2d(out_chs)
 
     def forward(self, x):
-        y = self.act1(self.bn1(self.conv_dw(x)))
-        y = self.bn2(self.conv_pw(self.se(y)))
-        return y + x if self.has_skip else y
+        y = self.se(self.act1(self.bn1(self.conv_dw(x))))
+        # projection + batch-norm (+ the block's input): one launch of the matrix-core kernel on the inference path
+        return conv1x1_bn(self.conv_pw, self.bn2, y, x if self.has_skip else None)
 
 
 class InvertedResidual(nn.Module):
@@ -54,21 +73,22 @@ class InvertedResidual(nn.Module):
         super().__init__()
         mid = in_chs * expand
         self.has_skip = stride == 1 and in_chs == out_chs
-        self.conv_pw = nn.Conv2d(in_chs, mid, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(mid)
-        self.act1 = nn.SiLU(inplace=True)
+        self.conv_pw = Conv1x1(in_chs, mid)
+        self.bn1 = BatchNormAct2d(mid, silu=True)
+        self.act1 = nn.Identity()
         self.conv_dw = DepthwiseConvKxK(mid, kernel, stride, dilation)
-        self.bn2 = nn.BatchNorm2d(mid)
-        self.act2 = nn.SiLU(inplace=True)
+        self.bn2 = BatchNormAct2d(mid, silu=True)
+        self.act2 = nn.Identity()
         self.se = SqueezeExcite(mid, max(1, round(in_chs * 0.25)))
-        self.conv_pwl = nn.Conv2d(mid, out_chs, 1, bias=False)
-        self.bn3 = nn.BatchNorm2d(out_chs)
+        self.conv_pwl = Conv1x1(mid, out_chs)
+        self.bn3 = BatchNormAct2d(out_chs)
 
     def forward(self, x):
-        y = self.act1(self.bn1(self.conv_pw(x)))
-        y = self.act2(self.bn2(self.conv_dw(y)))
-        y = self.bn3(self.conv_pwl(self.se(y)))
-        return y + x if self.has_skip else y
+        # expansion + batch-norm + SiLU and projection + batch-norm (+ the block's input): one launch of the matrix-core
+        # kernel each on the inference path; depthwise convolution and its batch-norm + SiLU: two launches
+        y = self.act1(conv1x1_bn(self.conv_pw, self.bn1, x))
+        y = self.se(self.act2(self.bn2(self.conv_dw(y))))
+        return conv1x1_bn(self.conv_pwl, self.bn3, y, x if self.has_skip else None)
 
 
 # (block type, repeats, out channels, kernel, stride) of EfficientNet-B0 before scaling
@@ -86,8 +106,8 @@ class EfficientNetB3Encoder(nn.Module):
         super().__init__()
         stem = _round_channels(32 * width)
         self.conv_stem = nn.Conv2d(in_channels, stem, 3, stride=2, padding=1, bias=False)
-        self.bn1 = nn.BatchNorm2d(stem)
-        self.act1 = nn.SiLU(inplace=True)
+        self.bn1 = BatchNormAct2d(stem, silu=True)
+        self.act1 = nn.Identity()
         stages = []
         prev = stem
         cur_stride, dilation = 2, 1
@@ -125,7 +145,8 @@ class EfficientNetB3Encoder(nn.Module):
         return [f"{prefix}.stem"] + [f"{prefix}.blocks.{i}.{len(self.blocks[i]) - 1}" for i in (1, 2, 4, 6)]
 
     def _stem(self, x):
-        return self.act1(self.bn1(self.conv_stem(x)))
+        y = conv3x3_bn(self.conv_stem, self.bn1, x)   # convolution + batch-norm + SiLU in one launch where that applies
+        return self.act1(self.bn1(self.conv_stem(x)) if y is None else y)
 
     def _forward_taped(self, x, tape) -> List[torch.Tensor]:
         names = iter(self._unit_names)
@@ -142,7 +163,7 @@ class EfficientNetB3Encoder(nn.Module):
         if self._tape is not None:
             return self._forward_taped(x, self._tape)
         f0 = x
-        f1 = self.act1(self.bn1(self.conv_stem(x)))
+        f1 = self._stem(x)
         y = self.blocks[1](self.blocks[0](f1))
         f2 = y
         f3 = self.blocks[2](f2)

@@ -36,9 +36,12 @@ class BatchNormAct2d(nn.BatchNorm2d):
     every other situation (training, gradients wanted, CPU, fp16 planes with an odd element count,
     mixed dtypes) the torch ops run one after the other."""
 
-    def __init__(self, num_features: int, relu: bool = False, **kwargs):
+    def __init__(self, num_features: int, relu: bool = False, silu: bool = False, **kwargs):
         super().__init__(num_features, **kwargs)
+        if relu and silu:
+            raise ValueError("one activation behind the batch-norm, not two")
         self.relu_after = relu
+        self.silu_after = silu   # y = silu( bn(x) [+ residual] ): the EfficientNet blocks
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None,
                 residual_norm: Optional[nn.BatchNorm2d] = None) -> torch.Tensor:
@@ -51,8 +54,8 @@ class BatchNormAct2d(nn.BatchNorm2d):
                                                                   and residual.is_contiguous())):
                 if residual_norm is None:
                     return ops.bn_act(x, self.running_mean, self.running_var, self.weight, self.bias, self.eps,
-                                      residual=residual, relu=self.relu_after)
-                if (residual is not None and not residual_norm.training and residual_norm.track_running_stats
+                                      residual=residual, relu=self.relu_after, act=2 if self.silu_after else 0)
+                if (residual is not None and not self.silu_after and not residual_norm.training and residual_norm.track_running_stats
                         and residual_norm.affine and residual_norm.weight.dtype == torch.float32
                         and residual_norm.running_mean.dtype == torch.float32
                         and residual_norm.num_features == self.num_features):
@@ -60,10 +63,12 @@ class BatchNormAct2d(nn.BatchNorm2d):
         y = super().forward(x)
         if residual is not None:
             y = y + (residual if residual_norm is None else residual_norm(residual))
+        if self.silu_after:
+            return F.silu(y)
         return F.relu(y) if self.relu_after else y
 
     def extra_repr(self) -> str:
-        return super().extra_repr() + f", relu={self.relu_after}"
+        return super().extra_repr() + f", relu={self.relu_after}" + (", silu=True" if self.silu_after else "")
 
 
 class DepthwiseConv3x3(nn.Conv2d):
@@ -284,7 +289,7 @@ def conv1x1_bn(conv: Conv1x1, bn: BatchNormAct2d, x, residual=None, residual_nor
             ok = ok and out.dtype == torch.float16
         pre = None
         if pre_norm is not None and x.dtype == torch.float16 and _plain_inference_norm(pre_norm) and not _hooked(pre_norm) \
-                and pre_norm.num_features == conv.in_channels:
+                and pre_norm.num_features == conv.in_channels and not pre_norm.silu_after:
             pre = pre_norm   # the extension falls back to a launch of its own where the kernel cannot take it along
         elif pre_norm is not None:
             x = pre_norm(x)
@@ -293,7 +298,8 @@ def conv1x1_bn(conv: Conv1x1, bn: BatchNormAct2d, x, residual=None, residual_nor
                 x = x.to(torch.float16)   # what autocast does to a convolution's input
             if x.is_contiguous():
                 return ops.conv1x1_bn_act(x, _fp16_matrix(conv._parameters["weight"]), bn, residual, residual_norm, bn.relu_after, out=out,
-                                          pre_bn=pre, pre_relu=pre.relu_after if pre is not None else False)
+                                          pre_bn=pre, pre_relu=pre.relu_after if pre is not None else False,
+                                          act=2 if bn.silu_after else 0)
         if pre is not None:
             x = pre_norm(x)
     elif pre_norm is not None:
@@ -346,7 +352,8 @@ def conv3x3_bn(conv: nn.Conv2d, bn: BatchNormAct2d, x):
         if x.dtype != torch.float16:
             x = x.to(torch.float16)   # what autocast does to a convolution's input
         if x.is_contiguous():
-            return ops.conv3x3_bn_act(x, _fp16_taps(conv._parameters["weight"]), bn, bn.relu_after, conv.stride[0], conv.dilation[0])
+            return ops.conv3x3_bn_act(x, _fp16_taps(conv._parameters["weight"]), bn, bn.relu_after, conv.stride[0], conv.dilation[0],
+                                      2 if bn.silu_after else 0)
     return None
 
 

@@ -618,13 +618,14 @@ _bn_fn = None
 
 
 def bn_act(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
-           eps: float, residual: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
-    """relu?(batch_norm(x, running statistics) [+ residual]) in one launch; a new tensor of x's dtype.
+           eps: float, residual: Optional[torch.Tensor] = None, relu: bool = False, act: int = 0) -> torch.Tensor:
+    """act?(batch_norm(x, running statistics) [+ residual]) in one launch; a new tensor of x's dtype.  `relu`, or
+    `act` = 1 (ReLU) / 2 (SiLU).
     Called ~60 times per forward of a ResNet-50 model: the argument checks are the extension's."""
     global _bn_fn
     if _bn_fn is None:
         _bn_fn = spice_ops().bn_act
-    return _bn_fn(x, mean, var, weight, bias, eps, residual, relu)
+    return _bn_fn(x, mean, var, weight, bias, eps, residual, relu, act)
 
 
 def bn_act_maxpool_supported(x: torch.Tensor) -> bool:
@@ -686,6 +687,13 @@ def depthwise_conv(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, dilat
     return spice_ops().depthwise_conv(x, weight, int(stride), int(dilation))
 
 
+def squeeze_excite(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
+    """x * sigmoid(conv1x1(silu(conv1x1(mean(x), w1, b1)), w2, b2)) for fp16 NCHW x and fp32 parameters (w1 [R,C,1,1] or
+    [R,C], w2 [C,R,1,1] or [C,R]): the squeeze-and-excite of an EfficientNet block in three launches, every
+    intermediate rounded to fp16 where torch's modules would store it under fp16 autocast."""
+    return spice_ops().squeeze_excite(x, w1, b1, w2, b2)
+
+
 _conv1x1_fn = None
 
 # Measurement hook (bench.py): a list to which every convolution call below appends
@@ -738,7 +746,7 @@ def _bn_parts(bn):
 def conv1x1_bn_act(x: torch.Tensor, weight2d: torch.Tensor, bn: "torch.nn.BatchNorm2d",
                    residual: Optional[torch.Tensor] = None, res_bn: Optional["torch.nn.BatchNorm2d"] = None,
                    relu: bool = False, route: int = 0, out: Optional[torch.Tensor] = None,
-                   pre_bn: Optional["torch.nn.BatchNorm2d"] = None, pre_relu: bool = False) -> torch.Tensor:
+                   pre_bn: Optional["torch.nn.BatchNorm2d"] = None, pre_relu: bool = False, act: int = 0) -> torch.Tensor:
     """relu?(bn(weight2d @ x') [+ residual | + res_bn(residual)]) from one call of the extension, with
     x' = x, or relu?(pre_bn(x)) when x is the raw result of the convolution before and its own batch-norm is still
     pending.  route 0: the matrix-core kernel that applies the tail to the product before storing it (and pre_bn to x
@@ -751,7 +759,7 @@ def conv1x1_bn_act(x: torch.Tensor, weight2d: torch.Tensor, bn: "torch.nn.BatchN
         _conv1x1_bn_fn = spice_ops().conv1x1_bn_act
     r = (None, None, None, None, 0.0) if res_bn is None else _bn_parts(res_bn)
     p = (None, None, None, None, 0.0) if pre_bn is None else _bn_parts(pre_bn)
-    args = (x, weight2d, *_bn_parts(bn), residual, *r, relu, route, out, *p, pre_relu)
+    args = (x, weight2d, *_bn_parts(bn), residual, *r, relu, route, out, *p, pre_relu, act)   # act: 1 ReLU, 2 SiLU
     if _conv_probe is not None:
         return _probed("matrix_core_pair", _conv1x1_bn_fn, args, x, weight2d.shape[0], weight2d.shape[1], residual)
     return _conv1x1_bn_fn(*args)
@@ -806,14 +814,14 @@ _conv3x3_fn = None
 
 
 def conv3x3_bn_act(x: torch.Tensor, weight9: torch.Tensor, bn: "torch.nn.BatchNorm2d", relu: bool = False,
-                   stride: int = 1, dilation: int = 1) -> torch.Tensor:
+                   stride: int = 1, dilation: int = 1, act: int = 0) -> torch.Tensor:
     """relu?(bn(conv2d(x, W, stride, padding=dilation, dilation))) for a 3x3 convolution without bias, fp16 NCHW, in ONE
     launch of the matrix-core kernel (nine shifted 1x1 products in one fp32 sum).  weight9: W as [Cout, 9 * Cin],
     tap-major (W.permute(0, 2, 3, 1)), fp16."""
     global _conv3x3_fn
     if _conv3x3_fn is None:
         _conv3x3_fn = spice_ops().conv3x3_bn_act
-    args = (x, weight9, *_bn_parts(bn), relu, stride, dilation)
+    args = (x, weight9, *_bn_parts(bn), relu, stride, dilation, act)   # act: 1 ReLU, 2 SiLU
     if _conv_probe is not None:
         return _probed("matrix_core_3x3", _conv3x3_fn, args, x, weight9.shape[0], weight9.shape[1])
     return _conv3x3_fn(*args)

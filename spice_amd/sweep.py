@@ -297,6 +297,8 @@ class SensitivitySweep:
                     continue
                 (_, _, h, w), in_dtype = self._geometry[mod]
                 dt = self.autocast_dtype or in_dtype
+                if self._served_inside_a_block(mod, dt):
+                    continue
                 if isinstance(mod, (Conv1x1, Conv1x1Bias, StemConv7x7)):
                     if mod.served_by_library(dt, h, w):
                         continue
@@ -304,6 +306,18 @@ class SensitivitySweep:
                     continue
                 return True
         return False
+
+    def _served_inside_a_block(self, mod: nn.Module, dtype: torch.dtype) -> bool:
+        """The two 1x1 convolutions of a squeeze-and-excite block never run as convolutions where the block's forward
+        is the library's (nets/efficientnet.py::SqueezeExcite)."""
+        owners = getattr(self, "_block_owner", None)
+        if owners is None:
+            owners = self._block_owner = {}
+            for m in self.model.modules():
+                if hasattr(m, "conv_reduce") and hasattr(m, "conv_expand") and hasattr(m, "served_by_library"):
+                    owners[m.conv_reduce] = owners[m.conv_expand] = m
+        owner = owners.get(mod)
+        return owner is not None and owner.served_by_library(dtype)
 
     # -- host preparation for a set of candidates: plans + one shared index upload
     # -- lanes: further copies of the network, each with its own launch plans and its own stream -------------
@@ -471,6 +485,8 @@ class SensitivitySweep:
             key = (n, cin, h, w, cout, groups, mod.kernel_size, mod.stride, mod.padding, mod.dilation)
             if key in self._warmed or groups == cin:  # depthwise convolutions do not go through MIOpen
                 continue
+            if self._served_inside_a_block(mod, self.autocast_dtype or in_dtype):
+                continue  # a squeeze-and-excite block's products: inside the library's own launches
             if isinstance(mod, (Conv1x1, Conv1x1Bias, StemConv7x7)) and mod.served_by_library(self.autocast_dtype or in_dtype, h, w):
                 continue  # a plain matrix product: no solver lookup to get out of the way
             if conv3x3_served_by_library(mod, self.autocast_dtype or in_dtype, h, w):

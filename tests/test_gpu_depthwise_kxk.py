@@ -102,3 +102,88 @@ def test_depthwise_kxk_entry_point_declines(dev):
     assert not ops.depthwise_conv_supported(x[:, :, :, :7].contiguous(), w[:, :, :3, :3].contiguous(), 1, 1)
     with pytest.raises(RuntimeError):
         ops.depthwise_conv(x, w, 1, 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_bn_act_with_silu_tail(dev, dtype, with_res):
+    """silu(bn(x) [+ residual]) in one launch against torch's batch-norm, add and SiLU kernels: the same rounding points
+    (batch-norm and sum rounded to the dtype before the activation), so at most one step of the dtype apart (the
+    exponential and the reciprocal are the hardware's 1-ulp instructions), and equal for nearly all elements."""
+    g = torch.Generator().manual_seed(7)
+    c = 24
+    x = (3.0 * torch.randn(4, c, 16, 20, generator=g)).to(dtype).to(dev)
+    res = (2.0 * torch.randn(4, c, 16, 20, generator=g)).to(dtype).to(dev) if with_res else None
+    mean, var = torch.randn(c, generator=g).to(dev), (torch.rand(c, generator=g) * 2 + 0.05).to(dev)
+    weight, bias = (torch.rand(c, generator=g) + 0.5).to(dev), torch.randn(c, generator=g).to(dev)
+    got = ops.bn_act(x, mean, var, weight, bias, 1e-5, residual=res, act=2)
+    there = F.batch_norm(x, mean, var, weight, bias, False, 0.0, 1e-5)
+    if with_res:
+        there = there + res
+    there = F.silu(there)
+    assert got.dtype == dtype
+    # (fp32: the three 1-ulp steps - exponential, reciprocal, product - add up to a few units of the last place)
+    tol = (2.0 ** -10 if dtype == torch.float16 else 2.0 ** -20) * there.float().abs().clamp_min(2.0 ** -14)
+    assert bool(((got.float() - there.float()).abs() <= tol).all())
+    assert float((got == there).float().mean()) > (0.99 if dtype == torch.float16 else 0.5)
+    # the ReLU code of the same argument still is ReLU
+    assert torch.equal(ops.bn_act(x, mean, var, weight, bias, 1e-5, act=1), ops.bn_act(x, mean, var, weight, bias, 1e-5, relu=True))
+
+
+@pytest.mark.parametrize("cin,cout,hw,with_res", [(40, 240, (32, 32), False), (240, 40, (32, 32), True),
+                                                    (136, 816, (16, 16), False), (33, 17, (8, 8), False)])
+def test_conv1x1_pair_with_silu_tail(dev, cin, cout, hw, with_res):
+    """The matrix-core pair kernel with the SiLU tail (EfficientNet's expansion) and with a plain residual behind the
+    batch-norm (its projection + skip): the SiLU of the kernel's own ReLU-free result, element for element."""
+    from spice_amd.nets import layers
+    torch.manual_seed(cin + cout)
+    conv = layers.Conv1x1(cin, cout).to(dev)
+    bn = layers.BatchNormAct2d(cout, silu=not with_res).to(dev).eval()
+    plain = layers.BatchNormAct2d(cout).to(dev).eval()
+    for m in (bn, plain):
+        m.running_mean.copy_(torch.linspace(-0.5, 0.5, cout)); m.running_var.copy_(torch.linspace(0.5, 1.5, cout))
+        m.weight.data.copy_(torch.linspace(0.7, 1.3, cout)); m.bias.data.copy_(torch.linspace(-0.3, 0.3, cout))
+    x = torch.randn(2, cin, *hw, device=dev).half()
+    res = torch.randn(2, cout, *hw, device=dev).half() if with_res else None
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        got = layers.conv1x1_bn(conv, bn, x, res)
+        base = layers.conv1x1_bn(conv, plain, x, res)
+    want = base if with_res else F.silu(base)
+    assert got.dtype == torch.float16 and got.shape == want.shape
+    tol = 2.0 ** -10 * want.float().abs().clamp_min(2.0 ** -14)
+    assert bool(((got.float() - want.float()).abs() <= tol).all())
+    if with_res:
+        assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("c,r,hw", [(40, 10, (64, 64)), (144, 6, (32, 32)), (816, 34, (16, 16)), (24, 6, (5, 7))])
+def test_squeeze_excite_in_three_launches(dev, c, r, hw):
+    """The block's forward through the library against torch's modules under fp16 autocast (mean, two convolutions
+    through MIOpen, SiLU, sigmoid, product): the gate within a few fp16 steps, the product with it; and against the
+    fp64 value of the same expression."""
+    from spice_amd.nets import layers
+    from spice_amd.nets.efficientnet import SqueezeExcite
+    torch.manual_seed(c + r)
+    se = SqueezeExcite(c, r).to(dev).eval()
+    se.conv_reduce.bias.data.normal_(0.0, 0.3); se.conv_expand.bias.data.normal_(0.0, 0.3)
+    x = torch.randn(3, c, *hw, device=dev).half()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        assert se.served_by_library(x.dtype)
+        got = se(x)
+        layers.set_library_forward(False)
+        try:
+            assert not se.served_by_library(x.dtype)
+            there = se(x)
+        finally:
+            layers.set_library_forward(True)
+    xd = x.double()
+    s = xd.mean((2, 3))
+    h = torch.nn.functional.silu(s @ se.conv_reduce.weight.double().reshape(r, c).t() + se.conv_reduce.bias.double())
+    g = torch.sigmoid(h @ se.conv_expand.weight.double().reshape(c, r).t() + se.conv_expand.bias.double())
+    exact = xd * g[:, :, None, None]
+    assert got.dtype == torch.float16 and got.shape == x.shape
+    scale = float(exact.abs().max())
+    assert float((got.double() - exact).abs().max()) <= 6e-3 * scale
+    assert float((got.float() - there.float()).abs().max()) <= 6e-3 * scale
+    with torch.autocast("cuda", dtype=torch.float16):
+        assert se(x.requires_grad_(True)).requires_grad   # gradients wanted: torch's modules

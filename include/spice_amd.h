@@ -426,14 +426,19 @@ int spice_depthwise_conv3x3_dilated(const void *x, const void *weight, int32_t w
  * MIOpen serves image by image with an unfold pass and a matrix product.  x [n, c, h, w] and y [n, c, oh, ow] fp16
  * contiguous, oh = (h - 1) / stride + 1, ow likewise; weight [c, 1, k, k] fp16 (1) or fp32 (0).  Same arithmetic as
  * spice_depthwise_conv3x3: the k * k products added to an fp32 sum in tap order, one rounding.  w must be even.
+ * mean / var / bn_weight / bn_bias (fp32 [c], or all NULL) + eps + act (0 none, 1 ReLU, 2 SiLU): the inference
+ * batch-norm and activation behind the convolution in the same launch, computed from the rounded result as
+ * spice_bn_act would from the stored tensor.
  * SPICE_ERR_UNSUPPORTED for every other kernel size, stride, dilation or width. */
 int spice_depthwise_conv_f16(const void *x, const void *weight, int32_t weight_dtype, void *y, int64_t n, int64_t c,
-                             int32_t h, int32_t w, int32_t kernel, int32_t stride, int32_t dilation, void *stream);
+                             int32_t h, int32_t w, int32_t kernel, int32_t stride, int32_t dilation, const float *mean,
+                             const float *var, const float *bn_weight, const float *bn_bias, float eps, int32_t act,
+                             void *stream);
 
 /* Squeeze-and-excite of the EfficientNet blocks, fp16 NCHW, inference: y = x * sigmoid(W2 silu(W1 mean(x) + b1) + b2),
  * mean over each plane; x, y [n, c, hw] fp16 contiguous, w1 [r, c], b1 [r], w2 [c, r], b2 [c] fp32 (rounded to fp16
  * where used, as autocast casts them).  Replaces torch's reduction, two 1x1 convolutions through MIOpen and four
- * element-wise launches with three launches; every intermediate is rounded to fp16 where torch's modules would store
+ * element-wise launches with four short launches; every intermediate is rounded to fp16 where torch's modules would store
  * it.  workspace: spice_squeeze_excite_workspace_bytes(n, c) bytes, 256-byte aligned.  c <= 4096, r <= 1024. */
 size_t spice_squeeze_excite_workspace_bytes(int64_t n, int64_t c);
 int spice_squeeze_excite_f16(const void *x, void *y, int64_t n, int64_t c, int64_t hw, const float *w1, const float *b1,

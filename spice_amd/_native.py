@@ -115,7 +115,8 @@ SIGNATURES = {
     "spice_squeeze_excite_f16": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64,
                                            c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "spice_depthwise_conv_f16": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int64, c_int32, c_int32,
-                                           c_int32, c_int32, c_int32, c_void_p]),
+                                           c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                           c_int32, c_void_p]),
     "spice_depthwise_conv3x3_dilated": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int64, c_int32,
                                                   c_int32, c_int32, c_void_p]),
     "spice_bn_act_maxpool_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,

@@ -10,6 +10,7 @@
 // the input window under it in LDS (32-bit loads from the even column at or left of the window; what lies outside the
 // plane is zero), and every lane sums four neighbouring outputs of one row from it.
 #include "common.h"
+#include "bn_math.h"
 
 #include <hip/hip_fp16.h>
 
@@ -26,6 +27,10 @@ struct DwkArgs {
     int txc_log2;      // lanes along a tile row: 16, 8 or 4 (tile 64, 32 or 16 outputs wide)
     int tiles_x, tiles_y;
     int w_is_f32;
+    // the batch-norm (+ activation) behind the convolution, applied to the rounded result before it is stored; null: none
+    const float *mean, *var, *weight, *bias;
+    float eps;
+    int act;   // tail code of bn_math.h: 0 none, 1 ReLU, 2 SiLU
 };
 
 template <int K, int S, int D>
@@ -106,6 +111,12 @@ __global__ __launch_bounds__(kDwkThreads) void depthwise_kxk_kernel(DwkArgs a) {
         asm volatile("" : "+v"(o));   // fp32 sum first, conversion as a step of its own
         out[e] = static_cast<_Float16>(o);
     }
+    if (a.mean != nullptr) {   // what a batch-norm launch behind this one would compute from the stored halves
+        const BnChannel p = bn_channel_of(a.mean, a.var, a.weight, a.bias, a.eps, static_cast<unsigned>(ch));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            out[e] = static_cast<_Float16>(bn_tail<_Float16, false, false>(static_cast<float>(out[e]), 0.0f, p, p, a.act));
+    }
     _Float16 *dst = a.y + (static_cast<int64_t>(plane) * a.oh + oy) * a.ow + ox;
     if ((a.ow & 3) == 0) {   // four outputs exist and lie on an 8-byte boundary
         typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
@@ -129,7 +140,8 @@ static void dwk_launch_d(int dilation, unsigned grid, hipStream_t st, const DwkA
 
 extern "C" int spice_depthwise_conv_f16(const void *x, const void *weight, int32_t weight_dtype, void *y, int64_t n,
                                         int64_t c, int32_t h, int32_t w, int32_t kernel, int32_t stride,
-                                        int32_t dilation, void *stream) {
+                                        int32_t dilation, const float *mean, const float *var, const float *bn_weight,
+                                        const float *bn_bias, float eps, int32_t act, void *stream) {
     using namespace spice;
     if (n < 0 || c <= 0 || h <= 0 || w <= 0) return SPICE_ERR_ARG;
     if ((kernel != 3 && kernel != 5) || (stride != 1 && stride != 2) || (dilation != 1 && dilation != 2))
@@ -137,6 +149,7 @@ extern "C" int spice_depthwise_conv_f16(const void *x, const void *weight, int32
     if (n == 0) return SPICE_OK;
     if (x == nullptr || weight == nullptr || y == nullptr) return SPICE_ERR_ARG;
     if (weight_dtype != 0 && weight_dtype != 1) return SPICE_ERR_UNSUPPORTED;
+    if (mean != nullptr && (var == nullptr || bn_weight == nullptr || bn_bias == nullptr)) return SPICE_ERR_ARG;
     // 32-bit loads of column pairs, 8-byte stores of four outputs: an even width, planes that start on those boundaries
     if ((w & 1) != 0 || !aligned16(x) || !aligned16(y)) return SPICE_ERR_UNSUPPORTED;
     const int oh = (h - 1) / stride + 1, ow = (w - 1) / stride + 1;
@@ -154,6 +167,12 @@ extern "C" int spice_depthwise_conv_f16(const void *x, const void *weight, int32
     a.tiles_x = static_cast<int>(ceil_div(ow, tw));
     a.tiles_y = static_cast<int>(ceil_div(oh, th));
     a.w_is_f32 = weight_dtype == 0;
+    a.mean = mean;
+    a.var = var;
+    a.weight = bn_weight;
+    a.bias = bn_bias;
+    a.eps = eps;
+    a.act = tail_code(act);
     {   // the largest window of a tile must fit the LDS array
         const int pad_span = (kernel - 1) * dilation + 1;
         const int ih = (th - 1) * stride + pad_span;

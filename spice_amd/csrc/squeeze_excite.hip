@@ -6,8 +6,8 @@
 //     y = x * g
 // torch runs this as a reduction, two 1x1 convolutions on 1 x 1 planes through MIOpen (whose solver look-up a sweep
 // candidate with a new channel count triggers), three element-wise launches and the product: eight-odd launches per
-// block, 26 blocks per forward.  Here it is three: the plane means (a wave per plane), the two small products with
-// their activations (a workgroup per image), the product with x.  Every intermediate is rounded to fp16 where torch's
+// block, 26 blocks per forward.  Here it is four short ones: the plane means (a wave per plane), the hidden values (a
+// wave per value), the gate (a lane per channel), the product with x.  Every intermediate is rounded to fp16 where torch's
 // modules would have stored it under fp16 autocast (the mean, each convolution's result, each activation), sums in
 // fp32: within a few fp16 steps of torch's gate, which multiplies x.
 #include "common.h"
@@ -80,57 +80,59 @@ __global__ __launch_bounds__(kSeThreads) void se_mean_block_kernel(const _Float1
     }
 }
 
-// gate[n, i0 .. i0 + 255] from mean[n, :]: an image's channels in slabs of 256, a workgroup per slab (each computes
-// the R hidden values itself: R * C multiply-adds, less than a launch of their own would cost).  Eight hidden values
-// at a time with every lane's loads of the eight weight rows in flight together: the sums are short and the kernel
-// is all latency otherwise.
-__global__ __launch_bounds__(kSeThreads) void se_gate_kernel(const float *__restrict__ mean, const float *__restrict__ w1,
-                                                             const float *__restrict__ b1, const float *__restrict__ w2,
+// hidden[n, j] = silu(W1[j, :] . mean[n, :] + b1[j]): a wave per (image, hidden value), a lane's loads of the row
+// all in flight before the first sum (the sums are short: the kernel is latency, not arithmetic).  Weights rounded
+// to fp16 as autocast casts them.
+__global__ __launch_bounds__(kSeThreads) void se_hidden_kernel(const float *__restrict__ mean, const float *__restrict__ w1,
+                                                               const float *__restrict__ b1, float *__restrict__ hidden,
+                                                               int n_images, int c, int r) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int item = blockIdx.x * (kSeThreads / 64) + wave;
+    if (item >= n_images * r) return;
+    const int n = item / r, j = item - n * r;
+    const float *row = w1 + static_cast<int64_t>(j) * c;
+    const float *m = mean + static_cast<int64_t>(n) * c;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int i = lane;
+    for (; i + 192 < c; i += 256) {
+        float wv[4], mv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            wv[u] = row[i + 64 * u];
+            mv[u] = m[i + 64 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = __builtin_fmaf(se_round_half(wv[u]), mv[u], acc[u]);
+    }
+    for (; i < c; i += 64) acc[0] = __builtin_fmaf(se_round_half(row[i]), m[i], acc[0]);
+    float total = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+    if (lane == 0) {
+        const float pre = se_round_half(total + se_round_half(b1[j]));   // the convolution's fp16 result
+        hidden[item] = se_round_half(silu_f32(pre));
+    }
+}
+
+// gate[n, i] = sigmoid(W2[i, :] . hidden[n, :] + b2[i]): a lane per channel
+__global__ __launch_bounds__(kSeThreads) void se_gate_kernel(const float *__restrict__ hidden, const float *__restrict__ w2,
                                                              const float *__restrict__ b2, _Float16 *__restrict__ gate,
                                                              int c, int r, int slabs) {
-    __shared__ float s_mean[kSeMaxChannels];
     __shared__ float s_hidden[kSeMaxChannels / 4];
-    __shared__ float s_part[kSeThreads / 64][8];
-    const int n = blockIdx.x / slabs, slab = blockIdx.x - n * slabs;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < c; i += kSeThreads) s_mean[i] = mean[static_cast<int64_t>(n) * c + i];
+    const int n = blockIdx.x / slabs, slab = blockIdx.x - n * slabs, tid = threadIdx.x;
+    for (int j = tid; j < r; j += kSeThreads) s_hidden[j] = hidden[static_cast<int64_t>(n) * r + j];
     __syncthreads();
-    // hidden = silu(W1 mean + b1), weights rounded to fp16 as autocast casts them
-    for (int j0 = 0; j0 < r; j0 += 8) {
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int i = tid; i < c; i += kSeThreads) {
-            const float m = s_mean[i];
-            float wv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) wv[u] = j0 + u < r ? w1[static_cast<int64_t>(j0 + u) * c + i] : 0.0f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] = __builtin_fmaf(se_round_half(wv[u]), m, acc[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc[u] += __shfl_xor(acc[u], off);
-            if (lane == 0) s_part[wave][u] = acc[u];
-        }
-        __syncthreads();
-        if (tid < 8 && j0 + tid < r) {
-            float total = 0.0f;
-#pragma unroll
-            for (int k = 0; k < kSeThreads / 64; ++k) total += s_part[k][tid];
-            const float pre = se_round_half(total + se_round_half(b1[j0 + tid]));   // the convolution's fp16 result
-            s_hidden[j0 + tid] = se_round_half(silu_f32(pre));
-        }
-        __syncthreads();
-    }
-    // gate = sigmoid(W2 hidden + b2): a lane per channel of the slab
     const int i = slab * kSeThreads + tid;
     if (i >= c) return;
     const float *row = w2 + static_cast<int64_t>(i) * r;
     float acc4[4] = {0.f, 0.f, 0.f, 0.f};
     int j = 0;
-    for (; j + 4 <= r; j += 4) {
+    for (; j + 8 <= r; j += 8) {
+        float wv[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc4[u] = __builtin_fmaf(se_round_half(row[j + u]), s_hidden[j + u], acc4[u]);
+        for (int u = 0; u < 8; ++u) wv[u] = row[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc4[u & 3] = __builtin_fmaf(se_round_half(wv[u]), s_hidden[j + u], acc4[u & 3]);
     }
     for (; j < r; ++j) acc4[0] = __builtin_fmaf(se_round_half(row[j]), s_hidden[j], acc4[0]);
     const float pre = se_round_half((acc4[0] + acc4[1]) + (acc4[2] + acc4[3]) + se_round_half(b2[i]));
@@ -163,7 +165,8 @@ __global__ __launch_bounds__(kSeThreads) void se_scale_kernel(const _Float16 *__
 
 extern "C" size_t spice_squeeze_excite_workspace_bytes(int64_t n, int64_t c) {
     if (n < 0 || c < 0) return 0;
-    return static_cast<size_t>(n * c) * 4 + static_cast<size_t>(n * c) * 2 + 256;   // means (fp32), gate (fp16)
+    // means (fp32), gate (fp16), hidden values (fp32, at most 1,024 per image)
+    return static_cast<size_t>(n * c) * 4 + static_cast<size_t>(n * c) * 2 + static_cast<size_t>(n) * 4096 + 512;
 }
 
 extern "C" int spice_squeeze_excite_f16(const void *x, void *y, int64_t n, int64_t c, int64_t hw, const float *w1,
@@ -177,7 +180,11 @@ extern "C" int spice_squeeze_excite_f16(const void *x, void *y, int64_t n, int64
     if (workspace_bytes < spice_squeeze_excite_workspace_bytes(n, c)) return SPICE_ERR_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0) return SPICE_ERR_ARG;
     float *mean = static_cast<float *>(workspace);
-    _Float16 *gate = reinterpret_cast<_Float16 *>(static_cast<char *>(workspace) + ((static_cast<size_t>(n * c) * 4 + 15) & ~size_t{15}));
+    char *base = static_cast<char *>(workspace);
+    const size_t gate_at = (static_cast<size_t>(n * c) * 4 + 255) & ~size_t{255};
+    const size_t hidden_at = (gate_at + static_cast<size_t>(n * c) * 2 + 255) & ~size_t{255};
+    _Float16 *gate = reinterpret_cast<_Float16 *>(base + gate_at);
+    float *hidden = reinterpret_cast<float *>(base + hidden_at);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int planes = static_cast<int>(n * c);
     const _Float16 *xh = static_cast<const _Float16 *>(x);
@@ -186,8 +193,11 @@ extern "C" int spice_squeeze_excite_f16(const void *x, void *y, int64_t n, int64
     else
         hipLaunchKernelGGL(se_mean_kernel, dim3((planes + 3) / 4), dim3(kSeThreads), 0, st, xh, mean, planes, static_cast<int>(hw));
     const int slabs = static_cast<int>((c + kSeThreads - 1) / kSeThreads);
-    hipLaunchKernelGGL(se_gate_kernel, dim3(static_cast<unsigned>(n * slabs)), dim3(kSeThreads), 0, st, mean, w1, b1, w2, b2,
-                       gate, static_cast<int>(c), static_cast<int>(r), slabs);
+    const int items = static_cast<int>(n * r);
+    hipLaunchKernelGGL(se_hidden_kernel, dim3((items + 3) / 4), dim3(kSeThreads), 0, st, mean, w1, b1, hidden,
+                       static_cast<int>(n), static_cast<int>(c), static_cast<int>(r));
+    hipLaunchKernelGGL(se_gate_kernel, dim3(static_cast<unsigned>(n * slabs)), dim3(kSeThreads), 0, st, hidden, w2, b2, gate,
+                       static_cast<int>(c), static_cast<int>(r), slabs);
     const int64_t total = n * c * hw;
     const int vec = ((hw & 7) == 0 && aligned16(x) && aligned16(y)) ? 1 : 0;
     const int64_t work = vec ? (total >> 3) : total;

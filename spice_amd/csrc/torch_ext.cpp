@@ -557,7 +557,9 @@ std::tuple<Tensor, Tensor> bn_act_maxpool(const Tensor &x, const Tensor &mean, c
     return std::make_tuple(full, pooled);
 }
 
-Tensor depthwise_conv(const Tensor &x, const Tensor &weight, int64_t stride, int64_t dilation) {
+Tensor depthwise_conv(const Tensor &x, const Tensor &weight, int64_t stride, int64_t dilation,
+                      const c10::optional<Tensor> &mean, const c10::optional<Tensor> &var,
+                      const c10::optional<Tensor> &bn_weight, const c10::optional<Tensor> &bn_bias, double eps, int64_t act) {
     check_dev(x, "x", at::kHalf);
     TORCH_CHECK_TYPE(weight.scalar_type() == at::kHalf || weight.scalar_type() == at::kFloat,
                      "depthwise_conv: weight dtype ", weight.scalar_type(), " not supported");
@@ -571,9 +573,22 @@ Tensor depthwise_conv(const Tensor &x, const Tensor &weight, int64_t stride, int
     const int64_t oh = (x.size(2) - 1) / stride + 1, ow = (x.size(3) - 1) / stride + 1;
     Tensor out = at::empty({x.size(0), x.size(1), oh, ow}, x.options());
     const int32_t wcode = weight.scalar_type() == at::kFloat ? 0 : 1;
+    const float *bn[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (mean.has_value()) {
+        TORCH_CHECK_VALUE(var.has_value() && bn_weight.has_value() && bn_bias.has_value(),
+                          "depthwise_conv: the batch-norm needs all four vectors");
+        const Tensor *parts[4] = {&*mean, &*var, &*bn_weight, &*bn_bias};
+        for (int k = 0; k < 4; ++k) {
+            TORCH_CHECK_TYPE(parts[k]->scalar_type() == at::kFloat && parts[k]->device() == x.device() &&
+                                 parts[k]->numel() == x.size(1) && parts[k]->is_contiguous(),
+                             "depthwise_conv: the batch-norm vectors must be contiguous fp32 [C] on x's device");
+            bn[k] = parts[k]->data_ptr<float>();
+        }
+    }
     check_rc(spice_depthwise_conv_f16(x.data_ptr(), weight.data_ptr(), wcode, out.data_ptr(), x.size(0), x.size(1),
                                       (int32_t)x.size(2), (int32_t)x.size(3), (int32_t)weight.size(2), (int32_t)stride,
-                                      (int32_t)dilation, current_stream(x)),
+                                      (int32_t)dilation, bn[0], bn[1], bn[2], bn[3], (float)eps, (int32_t)act,
+                                      current_stream(x)),
              "spice_depthwise_conv_f16");
     return out;
 }
@@ -874,7 +889,8 @@ TORCH_LIBRARY(spice, m) {
     m.def("bn_act_maxpool(Tensor x, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, bool relu, "
           "bool want_full) -> (Tensor, Tensor)", &bn_act_maxpool);
     m.def("depthwise_conv3x3(Tensor x, Tensor weight, int dilation) -> Tensor", &depthwise_conv3x3);
-    m.def("depthwise_conv(Tensor x, Tensor weight, int stride, int dilation) -> Tensor", &depthwise_conv);
+    m.def("depthwise_conv(Tensor x, Tensor weight, int stride, int dilation, Tensor? mean=None, Tensor? var=None, "
+          "Tensor? bn_weight=None, Tensor? bn_bias=None, float eps=0.0, int act=0) -> Tensor", &depthwise_conv);
     m.def("squeeze_excite(Tensor x, Tensor w1, Tensor b1, Tensor w2, Tensor b2) -> Tensor", &squeeze_excite);
     m.def("conv1x1_f16(Tensor x, Tensor weight2d, int stride) -> Tensor", &conv1x1_f16);
     m.def("conv7x7_s2(Tensor x, Tensor weight2d) -> Tensor", &conv7x7_s2);

@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from .. import ops
 from . import layers
-from .layers import BatchNormAct2d, Conv1x1, DepthwiseConvKxK, conv1x1_bn, conv3x3_bn
+from .layers import BatchNormAct2d, Conv1x1, DepthwiseConvKxK, conv1x1_bn, conv3x3_bn, depthwise_bn
 
 
 def _round_channels(ch: float, divisor: int = 8) -> int:
@@ -28,7 +28,7 @@ class SqueezeExcite(nn.Module):
         self.conv_expand = nn.Conv2d(reduced, channels, 1)
 
     def served_by_library(self, x_dtype: torch.dtype) -> bool:
-        """Whether forward() on fp16 activations is the library's three launches (no MIOpen call, no solver lookup for
+        """Whether forward() on fp16 activations is the library's four short launches (no MIOpen call, no solver lookup for
         the two 1x1 convolutions)."""
         a, b = self.conv_reduce, self.conv_expand
         return (layers.library_forward() and type(a) is nn.Conv2d and type(b) is nn.Conv2d
@@ -62,7 +62,7 @@ class DepthwiseSeparable(nn.Module):
         self.bn2 = BatchNormAct2d(out_chs)
 
     def forward(self, x):
-        y = self.se(self.act1(self.bn1(self.conv_dw(x))))
+        y = self.se(self.act1(depthwise_bn(self.conv_dw, self.bn1, x)))   # depthwise + batch-norm + SiLU: one launch
         # projection + batch-norm (+ the block's input): one launch of the matrix-core kernel on the inference path
         return conv1x1_bn(self.conv_pw, self.bn2, y, x if self.has_skip else None)
 
@@ -84,10 +84,10 @@ class InvertedResidual(nn.Module):
         self.bn3 = BatchNormAct2d(out_chs)
 
     def forward(self, x):
-        # expansion + batch-norm + SiLU and projection + batch-norm (+ the block's input): one launch of the matrix-core
-        # kernel each on the inference path; depthwise convolution and its batch-norm + SiLU: two launches
+        # on the inference path: expansion + batch-norm + SiLU and projection + batch-norm (+ the block's input) one
+        # launch of the matrix-core kernel each, depthwise convolution + batch-norm + SiLU one launch of the tiled kernel
         y = self.act1(conv1x1_bn(self.conv_pw, self.bn1, x))
-        y = self.se(self.act2(self.bn2(self.conv_dw(y))))
+        y = self.se(self.act2(depthwise_bn(self.conv_dw, self.bn2, y)))
         return conv1x1_bn(self.conv_pwl, self.bn3, y, x if self.has_skip else None)
 
 

@@ -121,6 +121,28 @@ class DepthwiseConvKxK(nn.Conv2d):
         return super().forward(x)
 
 
+def depthwise_bn(conv: "DepthwiseConvKxK", bn: BatchNormAct2d, x):
+    """bn(conv(x)) for a depthwise k x k convolution and the batch-norm (+ ReLU / SiLU) behind it as ONE launch of the
+    library's tiled kernel on the inference path of a HIP device; the two modules one after the other in every other
+    situation (hooks, training, shapes the kernel declines)."""
+    if (isinstance(x, torch.Tensor) and _LIBRARY_FORWARD and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4
+            and not torch.nn.modules.module._global_forward_hooks and not (_hooked(conv) or _hooked(bn))
+            and type(conv) is DepthwiseConvKxK and _plain_inference_norm(bn)
+            and (x.dtype == torch.float16 or
+                 (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16))):
+        k, s, d = conv.kernel_size[0], conv.stride[0], conv.dilation[0]
+        pad = (k // 2) * d
+        if (conv.kernel_size == (k, k) and conv.stride == (s, s) and conv.dilation == (d, d) and conv.padding == (pad, pad)
+                and conv.padding_mode == "zeros" and conv._parameters["bias"] is None
+                and conv.groups == conv.in_channels == conv.out_channels == bn.num_features):
+            if x.dtype != torch.float16:
+                x = x.to(torch.float16)   # what autocast does to a convolution's input
+            w = conv._parameters["weight"]
+            if ops.depthwise_conv_supported(x, w, s, d):
+                return ops.depthwise_conv(x, w, s, d, bn, 2 if bn.silu_after else (1 if bn.relu_after else 0))
+    return bn(conv(x))
+
+
 # fp16 copies of convolution weights, per Parameter object: id -> (weak reference, version, [Cout, Cin * kh * kw] fp16).
 # The same bookkeeping autocast does for the weights it casts: one cast per Parameter and version, dropped
 # with the Parameter.

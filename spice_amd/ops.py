@@ -680,16 +680,20 @@ def depthwise_conv_supported(x: torch.Tensor, weight: torch.Tensor, stride: int,
             and x.shape[0] * x.shape[1] < (1 << 24))
 
 
-def depthwise_conv(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, dilation: int = 1) -> torch.Tensor:
+def depthwise_conv(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, dilation: int = 1,
+                   bn: Optional["torch.nn.BatchNorm2d"] = None, act: int = 0) -> torch.Tensor:
     """conv2d(x, weight, stride=stride, padding=(k // 2) * dilation, dilation=dilation, groups=C) for fp16 x and a
     k x k weight, k = 3 or 5: fp32 sums of the k * k products in tap order, one rounding (what torch's own depthwise
-    kernel computes)."""
-    return spice_ops().depthwise_conv(x, weight, int(stride), int(dilation))
+    kernel computes).  `bn` (+ `act`: 1 ReLU, 2 SiLU): the inference batch-norm and activation behind it in the same
+    launch, from the rounded result as bn_act would compute them from the stored tensor."""
+    if bn is None:
+        return spice_ops().depthwise_conv(x, weight, int(stride), int(dilation))
+    return spice_ops().depthwise_conv(x, weight, int(stride), int(dilation), *_bn_parts(bn), int(act))
 
 
 def squeeze_excite(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
     """x * sigmoid(conv1x1(silu(conv1x1(mean(x), w1, b1)), w2, b2)) for fp16 NCHW x and fp32 parameters (w1 [R,C,1,1] or
-    [R,C], w2 [C,R,1,1] or [C,R]): the squeeze-and-excite of an EfficientNet block in three launches, every
+    [R,C], w2 [C,R,1,1] or [C,R]): the squeeze-and-excite of an EfficientNet block in four short launches, every
     intermediate rounded to fp16 where torch's modules would store it under fp16 autocast."""
     return spice_ops().squeeze_excite(x, w1, b1, w2, b2)
 

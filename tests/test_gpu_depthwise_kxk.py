@@ -95,7 +95,8 @@ def test_depthwise_kxk_entry_point_declines(dev):
     st = torch.cuda.current_stream(dev).cuda_stream
 
     def call(k, s, d, wd=8):
-        return L.spice_depthwise_conv_f16(x.data_ptr(), w.data_ptr(), 1, y.data_ptr(), 1, 2, 8, wd, k, s, d, st)
+        return L.spice_depthwise_conv_f16(x.data_ptr(), w.data_ptr(), 1, y.data_ptr(), 1, 2, 8, wd, k, s, d,
+                                          None, None, None, None, 0.0, 0, st)
     assert call(7, 1, 1) == nat.ERR_UNSUPPORTED and call(3, 3, 1) == nat.ERR_UNSUPPORTED and call(3, 1, 4) == nat.ERR_UNSUPPORTED
     assert call(3, 1, 1, wd=7) == nat.ERR_UNSUPPORTED
     assert call(3, 1, 1) == 0
@@ -157,7 +158,7 @@ def test_conv1x1_pair_with_silu_tail(dev, cin, cout, hw, with_res):
 
 
 @pytest.mark.parametrize("c,r,hw", [(40, 10, (64, 64)), (144, 6, (32, 32)), (816, 34, (16, 16)), (24, 6, (5, 7))])
-def test_squeeze_excite_in_three_launches(dev, c, r, hw):
+def test_squeeze_excite_on_the_library_kernels(dev, c, r, hw):
     """The block's forward through the library against torch's modules under fp16 autocast (mean, two convolutions
     through MIOpen, SiLU, sigmoid, product): the gate within a few fp16 steps, the product with it; and against the
     fp64 value of the same expression."""
@@ -187,3 +188,26 @@ def test_squeeze_excite_in_three_launches(dev, c, r, hw):
     assert float((got.float() - there.float()).abs().max()) <= 6e-3 * scale
     with torch.autocast("cuda", dtype=torch.float16):
         assert se(x.requires_grad_(True)).requires_grad   # gradients wanted: torch's modules
+
+
+@pytest.mark.parametrize("k,stride,dilation,shape,act", [(3, 1, 1, (2, 40, 64, 64), 2), (5, 2, 1, (2, 144, 32, 32), 2),
+                                                          (5, 1, 2, (1, 816, 16, 16), 2), (3, 2, 1, (2, 24, 20, 36), 1),
+                                                          (3, 1, 1, (1, 8, 8, 8), 0)])
+def test_depthwise_kxk_with_the_batch_norm_in_the_same_launch(dev, k, stride, dilation, shape, act):
+    """Batch-norm (+ ReLU / SiLU) applied to the rounded convolution result before the store: bit for bit the
+    convolution launch followed by spice_bn_act with the same tail code; and through the modules."""
+    from spice_amd.nets import layers
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(k + stride + c)
+    x = torch.randn(shape, generator=g).half().to(dev)
+    conv = layers.DepthwiseConvKxK(c, k, stride, dilation).to(dev)
+    bn = layers.BatchNormAct2d(c, relu=act == 1, silu=act == 2).to(dev).eval()
+    bn.running_mean.copy_(torch.randn(c, generator=g)); bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+    bn.weight.data.copy_(torch.rand(c, generator=g) + 0.5); bn.bias.data.copy_(torch.randn(c, generator=g))
+    plain = ops.depthwise_conv(x, conv.weight.detach(), stride, dilation)
+    want = ops.bn_act(plain, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, act=act)
+    got = ops.depthwise_conv(x, conv.weight.detach(), stride, dilation, bn, act)
+    assert torch.equal(got, want)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        assert torch.equal(layers.depthwise_bn(conv, bn, x), want)
+        assert torch.equal(bn(conv(x)), want)

@@ -348,11 +348,14 @@ class SegmentationModel(nn.Module):
         if (not isinstance(x, torch.Tensor) or not x.is_cuda or torch.is_grad_enabled() or not layers.library_forward()
                 or not torch.is_autocast_enabled("cuda") or torch.get_autocast_dtype("cuda") != torch.float16
                 or type(self).forward is not SegmentationModel.forward
-                or not isinstance(head, nn.Sequential) or len(head) != 3 or not isinstance(head[1], BilinearUp)
+                or not isinstance(head, nn.Sequential) or len(head) != 3
+                or not (isinstance(head[1], BilinearUp) or type(head[1]) is nn.Identity)
                 or type(head[2]) is not nn.Identity or layers._hooked(head) or layers._hooked(head[1]) or layers._hooked(self)
                 or torch.nn.modules.module._global_forward_hooks):
             return None
         low = head[0](self.decoder(self.encoder(x)))
+        if type(head[1]) is nn.Identity:
+            return low, None                # a head without up-sampling (the U-Nets): these are the logits
         if low.dtype != torch.float16 or low.dim() != 4:
             return head[1](low), None   # finished the ordinary way
         return low.contiguous(), head[1]

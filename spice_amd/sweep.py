@@ -581,12 +581,9 @@ class SensitivitySweep:
         t0 = time.perf_counter()
         self.join_lanes()
         torch.cuda.synchronize(self.device)
-        # a network whose forward does not stop at its head's convolution (no up-sampling behind it, a head the
-        # library does not take) has no tail to hand to the one-launch kernel: nothing to capture
-        probe = self._forward_to_head(images)
-        if probe is None or probe[1] is None:
+        # a network whose forward cannot be taken apart from its tail (a head of another form, hooks): nothing to capture
+        if self._forward_to_head(images) is None:
             return info
-        del probe
         for lane in self._lanes:
             lane.fused_head = self.fused_head
             for k in range(1, len(tape)):
@@ -632,8 +629,8 @@ class SensitivitySweep:
                 self.model.attach_tape(tape.replay(k, given=statics))
                 try:
                     warm = self._forward_to_head(images)   # once eagerly: whatever the launches set up lazily exists before the capture
-                    if warm is None or warm[1] is None:
-                        return None   # (the forward does not stop at the head's convolution: nothing to capture)
+                    if warm is None:
+                        return None   # (the forward cannot be taken apart from its tail: nothing to capture)
                     del warm
                     side.wait_stream(stream)
                     if self._graph_pool is None:
@@ -654,8 +651,10 @@ class SensitivitySweep:
             warnings.warn(f"no launch graph from unit {names[k]}: {e}")
             torch.cuda.synchronize(self.device)
             return None
-        if parts is None or parts[1] is None:
+        if parts is None:
             return None
+        # (parts[1] is None where the head has no up-sampling: the graph ends in the logits, and the candidate's tail
+        # is the three launches behind it)
         g = _SuffixGraph(graph, statics, inputs, parts[0], parts[1])
         g.recording = getattr(tape, "recordings", 0)
         self._graphs[k] = g

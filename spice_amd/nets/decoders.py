@@ -244,7 +244,7 @@ class UnetDecoder(nn.Module):
 class FPNBlock(nn.Module):
     def __init__(self, pyramid_ch: int, skip_ch: int):
         super().__init__()
-        self.skip_conv = nn.Conv2d(skip_ch, pyramid_ch, 1)
+        self.skip_conv = layers.Conv1x1Bias(skip_ch, pyramid_ch)   # (1x1 with bias: the library's kernel on the inference path)
 
     def forward(self, x, skip):
         return F.interpolate(x, scale_factor=2.0, mode="nearest") + self.skip_conv(skip)
@@ -258,7 +258,11 @@ class Conv3x3GNReLU(nn.Module):
                                    nn.GroupNorm(32, out_ch), nn.ReLU(inplace=True))
 
     def forward(self, x):
-        x = self.block(x)
+        blk = self.block
+        y = None
+        if type(blk) is nn.Sequential and len(blk) == 3 and not (layers._hooked(blk) or layers._hooked(blk[1]) or layers._hooked(blk[2])):
+            y = layers.conv3x3_plain(blk[0], x)   # the convolution on the library's kernel; group-norm and ReLU on torch's
+        x = blk(x) if y is None else blk[2](blk[1](y))
         return x if self.up is None else self.up(x)
 
 
@@ -266,15 +270,15 @@ class FPNDecoder(nn.Module):
     def __init__(self, encoder_channels: Sequence[int], pyramid_ch: int = 256, seg_ch: int = 128):
         super().__init__()
         enc = list(encoder_channels)[::-1][:4]
-        self.p5 = nn.Conv2d(enc[0], pyramid_ch, 1)
+        self.p5 = layers.Conv1x1Bias(enc[0], pyramid_ch)
         self.p4 = FPNBlock(pyramid_ch, enc[1])
         self.p3 = FPNBlock(pyramid_ch, enc[2])
         self.p2 = FPNBlock(pyramid_ch, enc[3])
         blocks = []
         for n_up in (3, 2, 1, 0):
-            layers = [Conv3x3GNReLU(pyramid_ch, seg_ch, upsample=bool(n_up))]
-            layers += [Conv3x3GNReLU(seg_ch, seg_ch, upsample=True) for _ in range(1, n_up)]
-            blocks.append(nn.Sequential(*layers))
+            stack = [Conv3x3GNReLU(pyramid_ch, seg_ch, upsample=bool(n_up))]
+            stack += [Conv3x3GNReLU(seg_ch, seg_ch, upsample=True) for _ in range(1, n_up)]
+            blocks.append(nn.Sequential(*stack))
         self.seg_blocks = nn.ModuleList(blocks)
         self.dropout = nn.Dropout2d(0.2)
         self.out_channels = seg_ch

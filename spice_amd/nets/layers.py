@@ -379,6 +379,20 @@ def conv3x3_bn(conv: nn.Conv2d, bn: BatchNormAct2d, x):
     return None
 
 
+def conv3x3_plain(conv: nn.Conv2d, x):
+    """conv(x) for a 3x3 convolution without bias that no batch-norm follows (the FPN decoder's, in front of a
+    group-norm) as one launch of the library's matrix-core kernel on the inference path of a HIP device; None where
+    that does not apply, for the caller to run the module."""
+    if (isinstance(x, torch.Tensor) and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4
+            and not torch.nn.modules.module._global_forward_hooks and not _hooked(conv)
+            and conv3x3_served_by_library(conv, x.dtype, x.shape[2], x.shape[3])):
+        if x.dtype != torch.float16:
+            x = x.to(torch.float16)   # what autocast does to a convolution's input
+        if x.is_contiguous():
+            return ops.conv3x3_plain(x, _fp16_taps(conv._parameters["weight"]), conv.stride[0], conv.dilation[0])
+    return None
+
+
 class ConvBnAct(nn.Sequential):
     """Sequential(convolution, BatchNormAct2d); a 1x1 convolution and its batch-norm go through conv1x1_bn."""
 

@@ -296,7 +296,9 @@ class FPNDecoder(nn.Module):
 class SegmentationHead(nn.Sequential):
     def __init__(self, in_ch: int, classes: int, kernel: int, upsampling: int):
         up = BilinearUp(scale_factor=upsampling) if upsampling > 1 else nn.Identity()
-        conv = layers.Conv1x1Bias(in_ch, classes) if kernel == 1 else nn.Conv2d(in_ch, classes, kernel, padding=kernel // 2)
+        conv = (layers.Conv1x1Bias(in_ch, classes) if kernel == 1 else
+                layers.Conv3x3Bias(in_ch, classes) if kernel == 3 else
+                nn.Conv2d(in_ch, classes, kernel, padding=kernel // 2))
         super().__init__(conv, up, nn.Identity())
 
 

@@ -379,6 +379,35 @@ def conv3x3_bn(conv: nn.Conv2d, bn: BatchNormAct2d, x):
     return None
 
 
+class Conv3x3Bias(nn.Conv2d):
+    """nn.Conv2d(in_ch, out_ch, 3, padding=1) with its bias: the convolution of a segmentation head that has no
+    up-sampling behind it (the U-Nets).  On fp16 activations (autocast) under no_grad on a HIP device, a width that is
+    a multiple of 8, the forward is one launch of the library's matrix-core kernel with the bias added where a
+    batch-norm's shift would be.  In every other situation torch's conv2d runs."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__(in_channels, out_channels, 3, padding=1, bias=True)
+
+    def served_by_library(self, x_dtype: torch.dtype, height: int, width: int) -> bool:
+        """Whether forward() on a plane of this size is a launch of the library (no MIOpen call, no solver lookup)."""
+        b = self._parameters["bias"]
+        return (_LIBRARY_FORWARD and _LIBRARY_CONV3X3 and b is not None and b.dtype == torch.float32 and self.groups == 1
+                and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1)
+                and self.dilation == (1, 1) and self.padding_mode == "zeros" and width % 8 == 0 and width >= 8
+                and (x_dtype == torch.float16 or
+                     (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16))
+                and _within_kernel_offsets(self.in_channels, self.out_channels, 9, height, width, 1))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if (not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4
+                and self.served_by_library(x.dtype, x.shape[2], x.shape[3])):
+            if x.dtype != torch.float16:
+                x = x.to(torch.float16)   # what autocast does to a convolution's input
+            if x.is_contiguous():
+                return ops.conv3x3_bias(x, _fp16_taps(self._parameters["weight"]), self._parameters["bias"])
+        return super().forward(x)
+
+
 def conv3x3_plain(conv: nn.Conv2d, x):
     """conv(x) for a 3x3 convolution without bias that no batch-norm follows (the FPN decoder's, in front of a
     group-norm) as one launch of the library's matrix-core kernel on the inference path of a HIP device; None where

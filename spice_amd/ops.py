@@ -792,6 +792,24 @@ def conv1x1_bias(x: torch.Tensor, weight2d: torch.Tensor, bias: torch.Tensor) ->
     return _conv1x1_bn_fn(*args)
 
 
+def conv3x3_bias(x: torch.Tensor, weight9: torch.Tensor, bias: torch.Tensor, stride: int = 1, dilation: int = 1) -> torch.Tensor:
+    """conv2d(x, W, bias, stride, padding=dilation, dilation) for a 3x3 convolution with an fp32 bias (a segmentation
+    head's), fp16 NCHW: one launch of the matrix-core kernel, the bias where a batch-norm's shift would be (the sums,
+    rounded to fp16 as a stored convolution result is, plus the bias in fp32, rounded to fp16)."""
+    global _conv3x3_fn
+    if _conv3x3_fn is None:
+        _conv3x3_fn = spice_ops().conv3x3_bn_act
+    key = (x.device, int(weight9.shape[0]))
+    unit = _UNIT_NORMS.get(key)
+    if unit is None:
+        unit = _UNIT_NORMS[key] = (torch.zeros(key[1], dtype=torch.float32, device=x.device),
+                                   torch.ones(key[1], dtype=torch.float32, device=x.device))
+    args = (x, weight9, unit[0], unit[1], unit[1], bias, 0.0, False, stride, dilation, 0)
+    if _conv_probe is not None:
+        return _probed("matrix_core_3x3", _conv3x3_fn, args, x, weight9.shape[0], weight9.shape[1])
+    return _conv3x3_fn(*args)
+
+
 def conv3x3_plain(x: torch.Tensor, weight9: torch.Tensor, stride: int = 1, dilation: int = 1) -> torch.Tensor:
     """conv2d(x, W, stride, padding=dilation, dilation) for a 3x3 convolution without bias and with nothing behind it
     the kernel could take along (a group-norm follows), fp16 NCHW: one launch of the matrix-core kernel with the

@@ -38,7 +38,7 @@ from . import dist as sdist
 from . import ops
 from .engine import MagnitudeImportance, MagnitudePruner
 from .engine.pruner import SliceJob
-from .nets.layers import Conv1x1, Conv1x1Bias, StemConv7x7, conv3x3_served_by_library
+from .nets.layers import Conv1x1, Conv1x1Bias, Conv3x3Bias, StemConv7x7, conv3x3_served_by_library
 from .nets.prefix import PrefixTape, StopForward
 
 _LATER = object()   # SliceJob.build: the index buffer is handed over after the build
@@ -299,7 +299,7 @@ class SensitivitySweep:
                 dt = self.autocast_dtype or in_dtype
                 if self._served_inside_a_block(mod, dt):
                     continue
-                if isinstance(mod, (Conv1x1, Conv1x1Bias, StemConv7x7)):
+                if isinstance(mod, (Conv1x1, Conv1x1Bias, Conv3x3Bias, StemConv7x7)):
                     if mod.served_by_library(dt, h, w):
                         continue
                 elif conv3x3_served_by_library(mod, dt, h, w):
@@ -487,7 +487,7 @@ class SensitivitySweep:
                 continue
             if self._served_inside_a_block(mod, self.autocast_dtype or in_dtype):
                 continue  # a squeeze-and-excite block's products: inside the library's own launches
-            if isinstance(mod, (Conv1x1, Conv1x1Bias, StemConv7x7)) and mod.served_by_library(self.autocast_dtype or in_dtype, h, w):
+            if isinstance(mod, (Conv1x1, Conv1x1Bias, Conv3x3Bias, StemConv7x7)) and mod.served_by_library(self.autocast_dtype or in_dtype, h, w):
                 continue  # a plain matrix product: no solver lookup to get out of the way
             if conv3x3_served_by_library(mod, self.autocast_dtype or in_dtype, h, w):
                 continue  # the library's own 3x3 kernel (the bottlenecks' convolutions): likewise

@@ -1049,3 +1049,29 @@ def test_plan_upload_as_a_launch(dev):
     kept.append((big, ops.upload_staged([big], dev)[0]))
     for a, t in kept:
         assert np.array_equal(t.cpu().numpy(), a)
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(16, 21, 64, 64), (13, 5, 16, 24), (16, 19, 10, 12)])
+def test_head_3x3_convolution_with_bias_in_one_launch(dev, cin, cout, h, w):
+    """Conv3x3Bias (the U-Nets' head) under fp16 autocast: the matrix-core kernel's sums rounded to fp16, plus the bias
+    in fp32, rounded to fp16 - bit for bit the bias-free launch and a separate addition; within fp16 rounding of
+    torch's conv2d; torch's conv2d itself where the width is not a multiple of 8 or gradients are wanted."""
+    from spice_amd.nets import layers
+    torch.manual_seed(cin + cout + w)
+    conv = layers.Conv3x3Bias(cin, cout).to(dev)
+    conv.bias.data.normal_(0.0, 0.5)
+    x = torch.randn(2, cin, h, w, device=dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        served = conv.served_by_library(x.dtype, h, w)
+        assert served == (w % 8 == 0)
+        got = conv(x)
+        there = torch.nn.functional.conv2d(x, conv.weight, conv.bias, padding=1)
+        if served:
+            w9 = conv.weight.detach().half().permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()
+            want = (ops.conv3x3_plain(x.half(), w9).float() + conv.bias.view(1, -1, 1, 1)).half()
+            assert torch.equal(got, want)
+    assert got.dtype == torch.float16 and got.shape == (2, cout, h, w)
+    step = 2e-3 * max(1.0, float(there.float().abs().max()))
+    assert float((got.float() - there.float()).abs().max()) <= step
+    with torch.autocast("cuda", dtype=torch.float16):
+        assert conv(x).requires_grad

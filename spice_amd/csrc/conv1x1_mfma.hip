@@ -1115,6 +1115,12 @@ extern "C" int spice_conv7x7_stride2_f16(const void *x, const void *weight, void
                           nullptr, 0.0f, 0, kStem7x7, 0, stream);
 }
 
+namespace spice {
+int conv3x3_narrow_launch(const void *x, const void *weight9, void *y, int64_t n, int64_t cin, int32_t h, int32_t w,
+                          int64_t cout, const float *mean, const float *var, const float *bn_weight,
+                          const float *bn_bias, float eps, int32_t relu, void *stream);   // conv3x3_narrow.hip
+}
+
 SPICE_ENV_KNOB(c3_halo_knob, "SPICE_CONV3X3_HALO", 1)        // 0 = the 3x3 convolutions stay with the first form
 SPICE_ENV_KNOB(c3_halo_form_knob, "SPICE_CONV3X3_HALO_FORM", 0)   // 2 | 3 = that tile shape wherever it applies (A/B measurements)
 
@@ -1208,6 +1214,10 @@ extern "C" int spice_conv3x3_bn_act_f16(const void *x, const void *weight9, void
     // whole stride cells; rows of the result that are whole 16-byte pieces; the in-row start of an edge load needs 8 columns
     if (h % stride != 0 || w % stride != 0 || ((w / stride) & 7) != 0 || w < 8) return SPICE_ERR_UNSUPPORTED;
     if (cin > (1 << 16)) return SPICE_ERR_UNSUPPORTED;
+    if (stride == 1 && dilation == 1 && cout <= 32) {   // the form for narrow layers (conv3x3_narrow.hip)
+        const int rc = spice::conv3x3_narrow_launch(x, weight9, y, n, cin, h, w, cout, mean, var, bn_weight, bn_bias, eps, relu, stream);
+        if (rc != SPICE_ERR_UNSUPPORTED) return rc;
+    }
     if (stride == 1) {
         const int rc = conv3x3_halo_launch(x, weight9, y, n, cin, h, w, cout, dilation, mean, var, bn_weight, bn_bias, eps, relu, stream);
         if (rc != SPICE_ERR_UNSUPPORTED) return rc;

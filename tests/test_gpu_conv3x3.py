@@ -45,7 +45,11 @@ CASES = [(2, 16, 8, 16, 24, 1, 1), (1, 64, 16, 16, 64, 1, 1), (1, 40, 8, 8, 130,
          (8, 32, 64, 64, 128, 1, 1), (6, 40, 64, 64, 100, 1, 2),
          # the patch form (x staged once per 64 input channels, nine taps out of it; taken from 512 input channels on):
          # dilation 2 on 32 x 32; an M tail; rows that do not fill the last tile, dilation 3; one 128-pixel row per tile
-         (2, 512, 32, 32, 512, 1, 2), (1, 512, 16, 16, 200, 1, 1), (1, 576, 10, 64, 130, 1, 3), (1, 512, 5, 128, 96, 1, 1)]
+         (2, 512, 32, 32, 512, 1, 2), (1, 512, 16, 16, 200, 1, 1), (1, 576, 10, 64, 130, 1, 3), (1, 512, 5, 128, 96, 1, 1),
+         # the form for at most 32 output channels (4 x 128-pixel tiles of whole patches, blocks of 16 or 32 input
+         # channels): columns and rows that do not fill the last tile; several blocks; one tile row; 21 and 32 channels
+         (1, 32, 12, 136, 16, 1, 1), (2, 128, 8, 256, 32, 1, 1), (1, 16, 9, 512, 21, 1, 1), (1, 48, 6, 128, 20, 1, 1),
+         (3, 64, 3, 264, 32, 1, 1), (2, 16, 64, 64, 1, 1, 1)]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -65,7 +69,8 @@ def test_conv3x3_exact_on_integer_data(dev, case, relu):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 32, 32, 64, 1, 1), (2, 128, 32, 64, 128, 2, 1), (1, 256, 32, 32, 512, 1, 2),
-                                  (8, 64, 128, 128, 64, 1, 1), (2, 512, 32, 32, 512, 1, 2)])
+                                  (8, 64, 128, 128, 64, 1, 1), (2, 512, 32, 32, 512, 1, 2), (2, 32, 256, 256, 16, 1, 1),
+                                  (1, 128, 64, 128, 32, 1, 1)])
 def test_conv3x3_on_random_data(dev, case):
     n, cin, h, w, cout, stride, dil = case
     g = torch.Generator().manual_seed(sum(case) + 3)

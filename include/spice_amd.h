@@ -508,7 +508,9 @@ int spice_conv7x7_stride2_f16(const void *x, const void *weight, void *y, int64_
  * weight9 is the convolution's weight as [Cout][9][Cin] (tap-major: weight.permute(0, 2, 3, 1)), fp16.
  * stride 1 or 2, dilation 1..7; h and w multiples of the stride, w / stride a multiple of 8, w >= 8; else
  * SPICE_ERR_UNSUPPORTED (callers keep torch's convolution).  fp32 sums in (tap, channel) order; mean == NULL: no
- * batch-norm.  Holds no state and uses no scratch memory. */
+ * batch-norm.  Layers of at most 32 output channels (stride 1, dilation 1, Cin a multiple of 16: the last decoder
+ * blocks and the 3x3 head of the U-Net models) take a kernel of their own (tiles of 4 x 128 pixels of all channels,
+ * the patch under a tile staged once per block of input channels).  Holds no state and uses no scratch memory. */
 int spice_conv3x3_bn_act_f16(const void *x, const void *weight9, void *y, int64_t n, int64_t cin, int32_t h,
                              int32_t w, int64_t cout, int32_t stride, int32_t dilation, const float *mean,
                              const float *var, const float *bn_weight, const float *bn_bias, float eps,

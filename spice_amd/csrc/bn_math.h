@@ -62,4 +62,39 @@ __device__ __forceinline__ float bn_tail(float x, float r, const BnChannel &p, c
     return v;
 }
 
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+// bn_tail of bn_math.h for two neighbouring pixels of one channel at once, value for value the same: the fp32 steps
+// as packed operations, every rounding to fp16 a conversion of its own (never folded into the multiply-add before
+// it), the clamp on the rounded halves (rounding is monotonic and keeps 0 and NaN, so max-then-round and
+// round-then-max agree).
+template <bool HAS_RES, bool RES_BN>
+__device__ __forceinline__ half2_t bn_tail_pair(half2_t x, half2_t r, const BnChannel &p, const BnChannel &q, int relu) {
+    const float2_t xf = {static_cast<float>(x[0]), static_cast<float>(x[1])};
+    const float2_t t = (xf - float2_t{p.mean, p.mean}) * float2_t{p.inv, p.inv};
+    float2_t o = __builtin_elementwise_fma(float2_t{p.weight, p.weight}, t, float2_t{p.bias, p.bias});
+    asm volatile("" : "+v"(o));
+    half2_t v = {static_cast<_Float16>(o[0]), static_cast<_Float16>(o[1])};
+    if constexpr (HAS_RES) {
+        float2_t rf = {static_cast<float>(r[0]), static_cast<float>(r[1])};
+        if constexpr (RES_BN) {
+            const float2_t rt = (rf - float2_t{q.mean, q.mean}) * float2_t{q.inv, q.inv};
+            float2_t ro = __builtin_elementwise_fma(float2_t{q.weight, q.weight}, rt, float2_t{q.bias, q.bias});
+            asm volatile("" : "+v"(ro));
+            const half2_t rh = {static_cast<_Float16>(ro[0]), static_cast<_Float16>(ro[1])};
+            rf = float2_t{static_cast<float>(rh[0]), static_cast<float>(rh[1])};
+        }
+        float2_t sum = float2_t{static_cast<float>(v[0]), static_cast<float>(v[1])} + rf;
+        asm volatile("" : "+v"(sum));
+        v = half2_t{static_cast<_Float16>(sum[0]), static_cast<_Float16>(sum[1])};
+    }
+    if (relu == 1) v = __builtin_elementwise_maximum(v, half2_t{0, 0});   // NaN-propagating maximum
+    else if (relu == 2) {   // SiLU on the rounded halves, in fp32, rounded again (bn_math.h)
+        const float2_t f = {silu_f32(static_cast<float>(v[0])), silu_f32(static_cast<float>(v[1]))};
+        v = half2_t{static_cast<_Float16>(f[0]), static_cast<_Float16>(f[1])};
+    }
+    return v;
+}
+
 }  // namespace spice

@@ -77,12 +77,63 @@ __device__ __forceinline__ uint4 nw_transpose8(uint4 v, int lane) {
     return make_uint4(d0, d1, d2, d3);
 }
 
+// The tile's C image [channel][pixel] -> 16-byte row pieces -> batch-norm tail -> memory.  ACT: -1 the plain product,
+// else the tail code (a constant here: no branch per pair of values).  Every store is issued - outside the image or
+// beyond the last channel it goes outside the descriptor and is dropped - so the pieces' reads, tails and stores
+// of a lane are one straight run of instructions.
+template <int ACT>
+__device__ __forceinline__ void nw_store_tile(const _Float16 *Cs, const float4 *bn_lds, const NwArgs &a, size_t img, int x0,
+                                              int y0, int tid) {
+    const int W = a.w_px, plane = a.h * W;
+    const __amdgpu_buffer_rsrc_t y_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(a.y + img * static_cast<size_t>(a.M) * plane, 0, a.M * plane * 2, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = tid + kNwThreads * i;
+        const int m = q >> 6, pp = q & 63;
+        const int row = pp >> 4, col = (pp & 15) * 8;
+        const bool in = m < a.M && y0 + row < a.h && x0 + col < W;
+        const uint4 c = *reinterpret_cast<const uint4 *>(Cs + m * kNwCPitch + row * kNwCols + col);
+        unsigned d[4] = {c.x, c.y, c.z, c.w};
+        if constexpr (ACT >= 0) {
+            const float4 c4 = bn_lds[m];   // (beyond the last channel: whatever the array holds; the store is dropped)
+            const BnChannel pch = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const half2_t in2 = __builtin_bit_cast(half2_t, d[e]);
+                const half2_t out2 = bn_tail_pair<false, false>(in2, half2_t{0, 0}, pch, pch, ACT);
+                d[e] = __builtin_bit_cast(unsigned, out2);
+            }
+        }
+        const u32x4_t raw = {d[0], d[1], d[2], d[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(raw, y_rsrc, in ? (m * plane + (y0 + row) * W + x0 + col) * 2 : kNwOutside, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void nw_store_tile_any(const _Float16 *Cs, const float4 *bn_lds, const NwArgs &a, size_t img,
+                                                  int x0, int y0, int tid) {
+    if (a.mean == nullptr) nw_store_tile<-1>(Cs, bn_lds, a, img, x0, y0, tid);
+    else if (a.relu == 0) nw_store_tile<0>(Cs, bn_lds, a, img, x0, y0, tid);
+    else if (a.relu == 1) nw_store_tile<1>(Cs, bn_lds, a, img, x0, y0, tid);
+    else nw_store_tile<2>(Cs, bn_lds, a, img, x0, y0, tid);
+}
+
+// The channels' batch-norm constants into LDS (read behind at least one barrier).
+__device__ __forceinline__ void nw_stage_bn(float4 *bn_lds, const NwArgs &a, int tid) {
+    if (a.mean != nullptr && tid < a.M) {
+        const BnChannel p = bn_channel_of(a.mean, a.var, a.weight, a.bias, a.eps, static_cast<unsigned>(tid));
+        bn_lds[tid] = make_float4(p.mean, p.inv, p.weight, p.bias);
+    }
+}
+
 template <int CK, int OCC>
 __global__ __launch_bounds__(kNwThreads, OCC) void conv3x3_narrow_kernel(NwArgs a) {
     constexpr int NO = CK / 8, NKS = CK / 16, XP = CK + 8;
     constexpr int GROUPS = kNwPRows * kNwPieces * NO;   // groups of eight lanes' pieces per block of channels
     constexpr int ROUNDS = (GROUPS + 31) / 32;
-    __shared__ __attribute__((aligned(16))) _Float16 lds[nw_lds_halfs(CK)];
+    __shared__ __attribute__((aligned(16))) _Float16 lds[nw_lds_halfs(CK) + 256];
+    float4 *bn_lds = reinterpret_cast<float4 *>(lds + nw_lds_halfs(CK));
+    nw_stage_bn(bn_lds, a, threadIdx.x);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     // workgroups are dealt to the eight XCDs round-robin: neighbouring tiles (which share patch rows) go to ONE XCD's L2
     unsigned tile = blockIdx.x;
@@ -175,25 +226,10 @@ __global__ __launch_bounds__(kNwThreads, OCC) void conv3x3_narrow_kernel(NwArgs 
             *reinterpret_cast<nw_half4_t *>(Cs + (lane & 31) * kNwCPitch + wave * kNwCols + 32 * t + 8 * rq + 4 * h) = v;
         }
     __syncthreads();
-    const bool has_bn = a.mean != nullptr;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int q = tid + kNwThreads * i;
-        const int m = q >> 6, pp = q & 63;
-        const int row = pp >> 4, col = (pp & 15) * 8;
-        if (m >= a.M || y0 + row >= a.h || x0 + col >= W) continue;
-        nw_half8_t v = *reinterpret_cast<const nw_half8_t *>(Cs + m * kNwCPitch + row * kNwCols + col);
-        if (has_bn) {
-            const BnChannel pch = bn_channel_of(a.mean, a.var, a.weight, a.bias, a.eps, static_cast<unsigned>(m));
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                v[e] = static_cast<_Float16>(bn_tail<_Float16, false, false>(static_cast<float>(v[e]), 0.0f, pch, pch, a.relu));
-        }
-        *reinterpret_cast<nw_half8_t *>(a.y + (img * a.M + m) * static_cast<size_t>(plane) + static_cast<size_t>(y0 + row) * W + x0 + col) = v;
-    }
+    nw_store_tile_any(Cs, bn_lds, a, img, x0, y0, tid);
 }
 
-SPICE_ENV_KNOB(nw_knob, "SPICE_CONV3X3_NARROW", 1)   // 0 = layers of at most 32 output channels stay with the general kernel
+SPICE_ENV_KNOB(nw_knob, "SPICE_CONV3X3_NARROW", 1)   // 0 = layers of at most 32 output channels stay with the general kernel; 2 = this form wherever it applies
 
 // The narrow form where it applies, SPICE_ERR_UNSUPPORTED otherwise (the caller then takes the general kernel).
 int conv3x3_narrow_launch(const void *x, const void *weight9, void *y, int64_t n, int64_t cin, int32_t h, int32_t w,
@@ -208,7 +244,7 @@ int conv3x3_narrow_launch(const void *x, const void *weight9, void *y, int64_t n
     if ((cin & 15) != 0 || cin > 512 || (w & 7) != 0) return SPICE_ERR_UNSUPPORTED;
     if (!aligned16(x) || !aligned16(y) || !aligned16(weight9)) return SPICE_ERR_UNSUPPORTED;
     const int64_t limit = (int64_t{1} << 30) - (int64_t{1} << 20);
-    if (cin * static_cast<int64_t>(h) * w * 2 > limit) return SPICE_ERR_UNSUPPORTED;
+    if (cin * static_cast<int64_t>(h) * w * 2 > limit || cout * static_cast<int64_t>(h) * w * 2 > limit) return SPICE_ERR_UNSUPPORTED;
     NwArgs a;
     a.x = static_cast<const _Float16 *>(x);
     a.w = static_cast<const _Float16 *>(weight9);
@@ -227,6 +263,10 @@ int conv3x3_narrow_launch(const void *x, const void *weight9, void *y, int64_t n
     a.tiles_y = static_cast<int>(ceil_div(h, kNwRows));
     const int64_t total = static_cast<int64_t>(a.tiles_x) * a.tiles_y * n;
     if (total > INT32_MAX) return SPICE_ERR_UNSUPPORTED;
+    // deep sums on planes that give fewer tiles than there are compute units stay with the general kernel's K-deep
+    // pipeline (MI355X, batch 8: 512 -> 21 on 64 x 64, 128 tiles: 74 us here against 53; 256 -> 32 on 128 x 128, 256
+    // tiles: 51 against 86)
+    if (cin > 64 && total < device_cu_count() && nw_knob() != 2) return SPICE_ERR_UNSUPPORTED;
     a.total_tiles = static_cast<unsigned>(total);
     hipStream_t st = static_cast<hipStream_t>(stream);
     // blocks of 32 channels where there are several (fewer rounds of staging and barriers per tile: 101 against 105 us

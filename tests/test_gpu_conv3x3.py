@@ -143,6 +143,21 @@ print("ok")
 """
 
 
+def test_conv3x3_narrow_form_forced_on_few_tiles():
+    """The form for at most 32 output channels on layers it leaves to the general kernel by itself (deep sums on
+    fewer tiles than compute units): blocks of 32 input channels, several of them, M tails: exact on integer data."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _FORCED.replace("((2, 64, 16, 128, 64, 1), (1, 128, 8, 32, 40, 2), (2, 192, 12, 64, 70, 1), (1, 64, 4, 8, 16, 7))",
+                             "((2, 128, 8, 256, 32, 1), (1, 96, 6, 136, 21, 1), (1, 256, 5, 16, 7, 1), (3, 160, 4, 128, 32, 1))")
+    assert script != _FORCED
+    env = dict(os.environ, SPICE_CONV3X3_NARROW="2")
+    out = subprocess.run([sys.executable, "-c", script % root], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
 @pytest.mark.parametrize("form", ["2", "3"])
 def test_conv3x3_patch_form_forced_on_small_layers(form):
     """Both tile shapes of the patch form on layers it is not taken for by itself (SPICE_CONV3X3_HALO_FORM is read

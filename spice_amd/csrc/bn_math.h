@@ -97,4 +97,15 @@ __device__ __forceinline__ half2_t bn_tail_pair(half2_t x, half2_t r, const BnCh
     return v;
 }
 
+// The same for tail codes 0 and 1 without a branch on the code: the clamp as a lower bound, {0, 0} for ReLU and
+// {-inf, -inf} for none (the NaN-propagating maximum of a value and -inf is the value).
+__device__ __forceinline__ half2_t bn_lower_bound(int relu) {
+    const _Float16 lo = relu == 1 ? static_cast<_Float16>(0.0f) : -static_cast<_Float16>(__builtin_inff());
+    return half2_t{lo, lo};
+}
+template <bool HAS_RES, bool RES_BN>
+__device__ __forceinline__ half2_t bn_tail_pair_lb(half2_t x, half2_t r, const BnChannel &p, const BnChannel &q, half2_t lower) {
+    return __builtin_elementwise_maximum(bn_tail_pair<HAS_RES, RES_BN>(x, r, p, q, 0), lower);
+}
+
 }  // namespace spice

@@ -26,7 +26,10 @@
 //   output channels, which would leave half of a 128-channel tile's waves without rows; 6 = sixteen waves (32 x 32
 //   each) on 128 channels x 128 pixels: deep K where such tiles make one round of the compute units.
 //   Epilogue: accumulators -> fp16 -> LDS C image (8-byte writes) -> row-major 16-byte pieces -> tail -> global.
-//   The residual's pieces are requested before the products start, so they have arrived when the tail needs them.
+//   The residual's pieces are requested before the products start, the batch-norm constants of a lane's rows right
+//   behind the last K step, and which tail applies is decided once, outside the rows: behind the last barrier a
+//   lane's rows are one straight run of LDS reads, arithmetic and stores, with no wait for memory and no branch per
+//   pair of values (constants fetched row by row behind that barrier cost a round trip to memory per row).
 #include "bn_math.h"
 
 namespace spice {
@@ -544,6 +547,24 @@ __global__ __launch_bounds__(mm_threads(STAGES), MT == 1 ? 4 : 2) void conv1x1_b
         }
     }
 
+    // The batch-norm constants of the lane's rows (and of the residual's batch-norm), requested here - no row's
+    // request behind a branch (rows beyond M ask for the last channel's) - so that they arrive under the two barriers
+    // and the writes of the C image instead of costing a round trip to memory per row behind them.
+    // (the 3x3 and 7x7 modes, whose sums are long and whose registers are full, fetch them row by row instead)
+    constexpr bool RES_MODE = XMODE == kXPlain;   // only the plain 1x1 product is called with a residual
+    constexpr bool EARLY = !IS3 && !IS7;
+    float tail_p[EARLY ? ROWS : 1][4], tail_q[RES_MODE ? ROWS : 1][4];
+    if (EARLY && has_bn) {
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const int mi = min(m0 + e_row + RSTEP * i, a.M - 1);
+            tail_p[i][0] = a.mean[mi], tail_p[i][1] = a.var[mi], tail_p[i][2] = a.weight[mi], tail_p[i][3] = a.bias[mi];
+            if constexpr (RES_MODE) {
+                if (res_bn)
+                    tail_q[i][0] = a.r_mean[mi], tail_q[i][1] = a.r_var[mi], tail_q[i][2] = a.r_weight[mi], tail_q[i][3] = a.r_bias[mi];
+            }
+        }
+    }
     // accumulators -> fp16 (the rounding of a stored product) -> C image [channel][pixel], four pixels per write
     __syncthreads();
     _Float16 *Cs = lds;
@@ -564,42 +585,53 @@ __global__ __launch_bounds__(mm_threads(STAGES), MT == 1 ? 4 : 2) void conv1x1_b
     __syncthreads();
 
     if (e_p >= a.hw) return;
+    // The rows of a lane as one straight run: C pieces and constants from LDS, the tail, the stores.  Which tail is
+    // decided once, outside the rows; inside, only the store depends on the row (rows beyond M hold zeros and
+    // whatever constants the array has: computed and dropped).
+    _Float16 *yi = a.y + img * a.y_image_stride + e_p;
+    auto rows = [&](auto has_res_c, auto res_bn_c, auto silu_c) {
+        constexpr bool HR = decltype(has_res_c)::value, RB = decltype(res_bn_c)::value, SI = decltype(silu_c)::value;
+        const half2_t lower = bn_lower_bound(a.relu);
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-        const int row = e_row + RSTEP * i;
-        const int m = m0 + row;
-        if (m >= a.M) break;   // rows ascend with i
-        half8_t v = *reinterpret_cast<const half8_t *>(Cs + row * CP + e_pc);
-        if (has_bn) {
-            const BnChannel pch = bn_channel_of(a.mean, a.var, a.weight, a.bias, a.eps, m);
-            if (has_res) {
-                const half8_t r = __builtin_bit_cast(half8_t, rres[i]);
-                if (res_bn) {
-                    const BnChannel qch = bn_channel_of(a.r_mean, a.r_var, a.r_weight, a.r_bias, a.r_eps, m);
+        for (int i = 0; i < ROWS; ++i) {
+            const int row = e_row + RSTEP * i;
+            const int m = m0 + row;
+            const uint4 c = *reinterpret_cast<const uint4 *>(Cs + row * CP + e_pc);
+            BnChannel pch;
+            if constexpr (EARLY) pch = BnChannel{tail_p[i][0], __builtin_amdgcn_rsqf(fabsf(tail_p[i][1] + a.eps)), tail_p[i][2], tail_p[i][3]};
+            else pch = bn_channel_of(a.mean, a.var, a.weight, a.bias, a.eps, static_cast<unsigned>(min(m, a.M - 1)));
+            BnChannel qch = pch;
+            if constexpr (RB) qch = BnChannel{tail_q[i][0], __builtin_amdgcn_rsqf(fabsf(tail_q[i][1] + a.r_eps)), tail_q[i][2], tail_q[i][3]};
+            unsigned d[4] = {c.x, c.y, c.z, c.w};
+            const unsigned rr[4] = {rres[i].x, rres[i].y, rres[i].z, rres[i].w};
 #pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        const half2_t o = bn_tail_pair<true, true>(half2_t{v[e], v[e + 1]}, half2_t{r[e], r[e + 1]}, pch, qch, a.relu);
-                        v[e] = o[0];
-                        v[e + 1] = o[1];
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        const half2_t o = bn_tail_pair<true, false>(half2_t{v[e], v[e + 1]}, half2_t{r[e], r[e + 1]}, pch, pch, a.relu);
-                        v[e] = o[0];
-                        v[e + 1] = o[1];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    const half2_t o = bn_tail_pair<false, false>(half2_t{v[e], v[e + 1]}, half2_t{0, 0}, pch, pch, a.relu);
-                    v[e] = o[0];
-                    v[e + 1] = o[1];
-                }
+            for (int e = 0; e < 4; ++e) {
+                const half2_t x2 = __builtin_bit_cast(half2_t, d[e]);
+                const half2_t r2 = __builtin_bit_cast(half2_t, rr[e]);
+                const half2_t o2 = SI ? bn_tail_pair<HR, RB>(x2, r2, pch, qch, 2) : bn_tail_pair_lb<HR, RB>(x2, r2, pch, qch, lower);
+                d[e] = __builtin_bit_cast(unsigned, o2);
             }
+            if (m < a.M) *reinterpret_cast<uint4 *>(yi + static_cast<size_t>(m) * a.hw) = make_uint4(d[0], d[1], d[2], d[3]);
         }
-        *reinterpret_cast<half8_t *>(a.y + img * a.y_image_stride + static_cast<size_t>(m) * a.hw + e_p) = v;
+    };
+    using std::false_type;
+    using std::true_type;
+    if (!has_bn) {
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const int row = e_row + RSTEP * i;
+            const int m = m0 + row;
+            const uint4 c = *reinterpret_cast<const uint4 *>(Cs + row * CP + e_pc);
+            if (m < a.M) *reinterpret_cast<uint4 *>(yi + static_cast<size_t>(m) * a.hw) = c;
+        }
+    } else if (a.relu == 2) {
+        if (!has_res) rows(false_type{}, false_type{}, true_type{});
+        else if (!res_bn) rows(true_type{}, false_type{}, true_type{});
+        else rows(true_type{}, true_type{}, true_type{});
+    } else {
+        if (!has_res) rows(false_type{}, false_type{}, false_type{});
+        else if (!res_bn) rows(true_type{}, false_type{}, false_type{});
+        else rows(true_type{}, true_type{}, false_type{});
     }
 }
 
@@ -878,7 +910,8 @@ static void mm_launch(const spice::MmArgs &a, hipStream_t st) {
     using namespace spice;
     constexpr int bytes = mm_lds_bytes(STAGES, MT);
     const auto kernel = conv1x1_bn_act_mfma_kernel<STAGES, MT, XMODE, PRE, W_ODD>;
-    if constexpr (bytes > 64 * 1024)
+    // (beside the images a workgroup has up to 8 KB of static LDS: a pending batch-norm's constants)
+    if constexpr (bytes + 12 * 1024 >= 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     hipLaunchKernelGGL(kernel, dim3(a.total_tiles), dim3(mm_threads(STAGES)), bytes, st, a);
 }

@@ -301,6 +301,34 @@ def test_sweep_lanes_give_the_results_of_one_lane(dev):
     assert int(results[0]["confusion"][pick].sum()) == len(pick) * int((lab != 255).sum())
 
 
+def test_two_lane_sweep_repeats_the_one_lane_tables_at_the_benchmark_size(dev):
+    """Candidates 270-320 of the 414 of the DeepLabV3Plus_resnet sweep on the benchmark's batch (the groups of layer4,
+    whose pruned channel counts send the 1x1 kernel through its rarely taken forms and partly filled tiles), forwarded
+    whole, two at a time, six times over: every run gives the confusion matrices of the one-lane run.  (A form of the
+    1x1 kernel that fetched its batch-norm constants in front of the K loop broke exactly this, in about half of the
+    runs, while each kernel alone repeated itself.)"""
+    from spice_amd.sweep import DEFAULT_RATIOS
+    torch.manual_seed(1234)
+    model = nets.create_model("DeepLabV3Plus", "resnet50", 21).to(dev).eval()
+    ignored = [m for m in model.segmentation_head.modules() if isinstance(m, nn.Conv2d)]
+    x = torch.from_numpy(synth.normal(1234, 50, 8 * 3 * 512 * 512).reshape(8, 3, 512, 512)).to(dev)
+    lab = torch.from_numpy(synth.label_map(1234, 8, 512, 512, 21, "blocky", ignore_share=0.05)).to(dev)
+    pick = list(range(270, 320))
+
+    def tables(lanes):
+        sweep = SensitivitySweep(model, 21, DEFAULT_RATIOS, ignored_layers=ignored)
+        sweep.prefix_reuse = False
+        assert sweep.enable_lanes(lanes) == lanes
+        return sweep.run(x, lab, indices=pick)["confusion"][pick].clone()
+
+    one = tables(1)
+    assert torch.equal(one, tables(1))
+    for _ in range(6):
+        two = tables(2)
+        moved = (two - one).abs().sum((1, 2))
+        assert int(moved.max()) == 0, {pick[i]: int(moved[i]) for i in moved.nonzero().flatten().tolist()}
+
+
 def test_prune_model_end_to_end(dev, tmp_path):
     cfg = PruningConfig(model_name="DeepLabV3Plus_resnet", output_dir=str(tmp_path), data_root=str(tmp_path / "nodata"),
                         num_classes=5, input_size=(64, 64), example_input_size=(1, 3, 64, 64),

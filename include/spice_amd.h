@@ -445,6 +445,19 @@ int spice_squeeze_excite_f16(const void *x, void *y, int64_t n, int64_t c, int64
                              int64_t r, const float *w2, const float *b2, void *workspace, size_t workspace_bytes,
                              void *stream);
 
+/* The image-pooling branch of an ASPP (the DeepLabV3+ decoders of pruning/models.py:35-39): plane means of x
+ * [n, cin, hw] fp16 -> 1x1 convolution with weight [cout, cin] fp16 -> inference batch-norm (fp32 [cout] vectors, or
+ * all NULL) -> ReLU / SiLU (relu: 0 none, 1, 2) -> the result spread over the hw pixels of y [n, cout, hw] fp16, whose
+ * images lie y_image_stride elements apart (0: dense; a channel slice of a concatenation otherwise).  Two launches
+ * where torch's modules take a reduction, a convolution through MIOpen, a batch-norm, an activation and an
+ * up-sampling; fp32 sums, every intermediate rounded to fp16 where those modules store it.
+ * workspace: spice_pooled_branch_workspace_bytes(n, cin) bytes. */
+size_t spice_pooled_branch_workspace_bytes(int64_t n, int64_t cin);
+int spice_pooled_branch_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int64_t hw, int64_t cout,
+                            int64_t y_image_stride, const float *mean, const float *var, const float *bn_weight,
+                            const float *bn_bias, float eps, int32_t relu, void *workspace, size_t workspace_bytes,
+                            void *stream);
+
 /* ------------------------------------------------------------------------- *
  * (8) 1x1 stride-1 convolution of fp16 NCHW activations, without bias:
  *   y[n][Cout, HW] = weight[Cout, Cin] @ x[n][Cin, HW]   (fp32 accumulation).

@@ -111,6 +111,10 @@ SIGNATURES = {
                                     c_void_p]),
     "spice_depthwise_conv3x3": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int64, c_int32, c_int32,
                                           c_void_p]),
+    "spice_pooled_branch_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "spice_pooled_branch_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_void_p, c_size_t,
+                                          c_void_p]),
     "spice_squeeze_excite_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "spice_squeeze_excite_f16": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64,
                                            c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -161,7 +161,76 @@ __global__ __launch_bounds__(kSeThreads) void se_scale_kernel(const _Float16 *__
     }
 }
 
+// The image-pooling branch of an ASPP (pruning/models.py:35-39's DeepLabV3+ decoders): plane means -> 1x1 convolution
+// -> batch-norm -> ReLU -> the 1 x 1 result spread over the plane (bilinear up-sampling of a single pixel is that pixel).
+// A wave per (image, output channel): the dot product of the channel's fp16 weights with the image's means in fp32,
+// rounded to fp16 where the convolution stores it, the batch-norm tail of bn_math.h, and the plane written out.
+__global__ __launch_bounds__(kSeThreads) void pooled_branch_kernel(const float *__restrict__ mean, const _Float16 *__restrict__ w,
+                                                                   _Float16 *__restrict__ y, int items, int cin, int cout,
+                                                                   int hw, int64_t y_image_stride, const float *bn_mean,
+                                                                   const float *bn_var, const float *bn_weight,
+                                                                   const float *bn_bias, float eps, int relu) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int item = blockIdx.x * (kSeThreads / 64) + wave;
+    if (item >= items) return;
+    const int n = item / cout, co = item - n * cout;
+    const float *m = mean + static_cast<int64_t>(n) * cin;
+    const _Float16 *wr = w + static_cast<int64_t>(co) * cin;
+    float sum = 0.0f;
+    for (int k = lane; k < cin; k += 64) sum = __builtin_fmaf(static_cast<float>(wr[k]), m[k], sum);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    float v = se_round_half(sum);
+    if (bn_mean != nullptr) {
+        const BnChannel p = bn_channel_of(bn_mean, bn_var, bn_weight, bn_bias, eps, static_cast<unsigned>(co));
+        v = bn_tail<_Float16, false, false>(v, 0.0f, p, p, relu);
+    }
+    const _Float16 hv = static_cast<_Float16>(v);
+    _Float16 *dst = y + n * y_image_stride + static_cast<int64_t>(co) * hw;
+    if ((hw & 7) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+        const se_f16x8_t v8 = {hv, hv, hv, hv, hv, hv, hv, hv};
+        for (int i = lane; i < (hw >> 3); i += 64) reinterpret_cast<se_f16x8_t *>(dst)[i] = v8;
+    } else {
+        for (int i = lane; i < hw; i += 64) dst[i] = hv;
+    }
+}
+
 }  // namespace spice
+
+extern "C" size_t spice_pooled_branch_workspace_bytes(int64_t n, int64_t cin) {
+    if (n < 0 || cin < 0) return 0;
+    return static_cast<size_t>(n * cin) * 4 + 256;   // the means, fp32
+}
+
+extern "C" int spice_pooled_branch_f16(const void *x, const void *weight, void *y, int64_t n, int64_t cin, int64_t hw,
+                                       int64_t cout, int64_t y_image_stride, const float *mean, const float *var,
+                                       const float *bn_weight, const float *bn_bias, float eps, int32_t relu,
+                                       void *workspace, size_t workspace_bytes, void *stream) {
+    using namespace spice;
+    if (n < 0 || cin <= 0 || hw <= 0 || cout <= 0) return SPICE_ERR_ARG;
+    if (n == 0) return SPICE_OK;
+    if (!x || !weight || !y || !workspace) return SPICE_ERR_ARG;
+    if (mean != nullptr && (!var || !bn_weight || !bn_bias)) return SPICE_ERR_ARG;
+    if (y_image_stride == 0) y_image_stride = cout * hw;   // dense
+    if (y_image_stride < cout * hw) return SPICE_ERR_ARG;
+    if (hw > INT32_MAX || n * cin > INT32_MAX || n * cout > INT32_MAX) return SPICE_ERR_UNSUPPORTED;
+    if (workspace_bytes < spice_pooled_branch_workspace_bytes(n, cin)) return SPICE_ERR_WORKSPACE;
+    float *means = static_cast<float *>(workspace);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int planes = static_cast<int>(n * cin);
+    const _Float16 *xh = static_cast<const _Float16 *>(x);
+    if (hw >= 4096)
+        hipLaunchKernelGGL(se_mean_block_kernel, dim3(planes), dim3(kSeThreads), 0, st, xh, means, static_cast<int>(hw));
+    else
+        hipLaunchKernelGGL(se_mean_kernel, dim3((planes + 3) / 4), dim3(kSeThreads), 0, st, xh, means, planes, static_cast<int>(hw));
+    const int items = static_cast<int>(n * cout);
+    hipLaunchKernelGGL(pooled_branch_kernel, dim3((items + 3) / 4), dim3(kSeThreads), 0, st, means,
+                       static_cast<const _Float16 *>(weight), static_cast<_Float16 *>(y), items, static_cast<int>(cin),
+                       static_cast<int>(cout), static_cast<int>(hw), y_image_stride, mean, var, bn_weight, bn_bias, eps,
+                       tail_code(relu));
+    SPICE_LAUNCH_CHECK();
+    return SPICE_OK;
+}
 
 extern "C" size_t spice_squeeze_excite_workspace_bytes(int64_t n, int64_t c) {
     if (n < 0 || c < 0) return 0;

@@ -614,6 +614,33 @@ Tensor squeeze_excite(const Tensor &x, const Tensor &w1, const Tensor &b1, const
     return out;
 }
 
+// mean over the plane -> 1x1 convolution -> batch-norm -> activation -> spread over the plane, into `out` (a channel
+// slice of a concatenation) when given
+Tensor pooled_branch(const Tensor &x, const Tensor &weight2d, const Tensor &mean, const Tensor &var, const Tensor &weight,
+                     const Tensor &bias, double eps, int64_t act, const c10::optional<Tensor> &out_opt) {
+    check_dev(x, "x", at::kHalf);
+    check_dev(weight2d, "weight", at::kHalf);
+    check_same_device(x, weight2d, "weight");
+    TORCH_CHECK_VALUE(x.dim() == 4 && weight2d.dim() == 2 && weight2d.size(1) == x.size(1),
+                      "pooled_branch: x must be [N,Cin,H,W] and weight [Cout,Cin]");
+    const int64_t n = x.size(0), cin = x.size(1), h = x.size(2), w = x.size(3), c = weight2d.size(0);
+    for (const Tensor *p : {&mean, &var, &weight, &bias})
+        TORCH_CHECK_TYPE(p->scalar_type() == at::kFloat && p->device() == x.device() && p->numel() == c && p->is_contiguous(),
+                         "pooled_branch: the four parameter vectors must be contiguous fp32 [", c, "] on ", x.device());
+    c10::DeviceGuard guard(x.device());
+    if (out_opt.has_value()) check_slice_out(*out_opt, x, n, c, h, w, at::kHalf, "pooled_branch");
+    Tensor out = out_opt.has_value() ? *out_opt : at::empty({n, c, h, w}, x.options());
+    if (n == 0 || h * w == 0) return out;
+    const int64_t image_stride = out_opt.has_value() && n > 1 ? out.stride(0) : 0;
+    const size_t need = spice_pooled_branch_workspace_bytes(n, cin);
+    Tensor ws = at::empty({(int64_t)need}, x.options().dtype(at::kByte));
+    check_rc(spice_pooled_branch_f16(x.data_ptr(), weight2d.data_ptr(), out.data_ptr(), n, cin, h * w, c, image_stride,
+                                     mean.data_ptr<float>(), var.data_ptr<float>(), weight.data_ptr<float>(),
+                                     bias.data_ptr<float>(), (float)eps, (int32_t)act, ws.data_ptr(), need, current_stream(x)),
+             "spice_pooled_branch_f16");
+    return out;
+}
+
 Tensor depthwise_conv3x3(const Tensor &x, const Tensor &weight, int64_t dilation) {
     check_dev(x, "x", at::kHalf);
     TORCH_CHECK_TYPE(weight.scalar_type() == at::kHalf || weight.scalar_type() == at::kFloat,
@@ -892,6 +919,7 @@ TORCH_LIBRARY(spice, m) {
     m.def("depthwise_conv(Tensor x, Tensor weight, int stride, int dilation, Tensor? mean=None, Tensor? var=None, "
           "Tensor? bn_weight=None, Tensor? bn_bias=None, float eps=0.0, int act=0) -> Tensor", &depthwise_conv);
     m.def("squeeze_excite(Tensor x, Tensor w1, Tensor b1, Tensor w2, Tensor b2) -> Tensor", &squeeze_excite);
+    m.def("pooled_branch(Tensor x, Tensor weight2d, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, int act, Tensor? out) -> Tensor", &pooled_branch);
     m.def("conv1x1_f16(Tensor x, Tensor weight2d, int stride) -> Tensor", &conv1x1_f16);
     m.def("conv7x7_s2(Tensor x, Tensor weight2d) -> Tensor", &conv7x7_s2);
     m.def("conv3x3_bn_act(Tensor x, Tensor weight9, Tensor mean, Tensor var, Tensor weight, Tensor bias, float eps, "

@@ -77,12 +77,17 @@ class BilinearLike(nn.Upsample):
         return ops.upsample_bilinear(y.contiguous(), size=size, align_corners=False, out=out)
 
 
-def _writes_in_place(x) -> bool:
-    """Whether the producers of a concatenation may write their slices of it directly: real tensors on a HIP
-    device, inference, fp16 autocast (every producer's result is fp16 there, as the consumer convolution's cast of
-    the concatenation would make it)."""
+def _fp16_inference(x) -> bool:
+    """Real tensors on a HIP device, inference, fp16 autocast, the library's forward switched on."""
     return (isinstance(x, torch.Tensor) and layers.library_forward() and x.is_cuda and not torch.is_grad_enabled()
             and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16)
+
+
+def _writes_in_place(x) -> bool:
+    """Whether the producers of a concatenation may write their slices of it directly: fp16 inference on the
+    library's kernels (every producer's result is fp16 there, as the consumer convolution's cast of the
+    concatenation would make it)."""
+    return _fp16_inference(x)
 
 
 def _conv_bn_relu(conv: nn.Module, ch: int) -> nn.Sequential:
@@ -98,7 +103,18 @@ class ASPPPooling(nn.Module):
         self.relu = nn.ReLU()
         self.up = BilinearLike()
 
+    def served_by_library(self, x) -> bool:
+        """The whole branch in the library's two launches (ops.pooled_branch): inference under fp16 autocast on a
+        HIP device, the modules as built and not listened to."""
+        return (_fp16_inference(x) and x.dtype == torch.float16 and x.dim() == 4 and x.is_contiguous()
+                and not self.bn.training and type(self.relu) is nn.ReLU and type(self.pool) is nn.AdaptiveAvgPool2d
+                and self.conv.bias is None and self.conv.weight.is_cuda
+                and not any(layers._hooked(m) for m in (self.pool, self.conv, self.bn, self.relu, self.up)))
+
     def forward(self, x, out=None):
+        if self.served_by_library(x):
+            from .. import ops
+            return ops.pooled_branch(x, layers._fp16_matrix(self.conv.weight), self.bn, 1, out)
         y = self.relu(self.bn(self.conv(self.pool(x))))
         return self.up(y, x) if out is None else self.up(y, x, out=out)
 

@@ -341,7 +341,12 @@ def _fp16_taps(weight: torch.Tensor) -> torch.Tensor:
     key = id(weight)
     ent = _FP16_TAPS.get(key)
     if ent is None or ent[0]() is not weight or ent[1] != weight._version:
-        w9 = weight.detach().to(torch.float16).permute(0, 2, 3, 1).reshape(weight.shape[0], 9 * weight.shape[1]).contiguous()
+        # the cast and the move of the taps in front of the channels in ONE copy launch (a sweep candidate makes this
+        # copy of its sliced 3x3 weights once per evaluation)
+        cout, cin = weight.shape[0], weight.shape[1]
+        w9 = torch.empty((cout, 3, 3, cin), dtype=torch.float16, device=weight.device)
+        w9.copy_(weight.detach().permute(0, 2, 3, 1))
+        w9 = w9.view(cout, 9 * cin)
         ent = (weakref.ref(weight, lambda _, k=key: _FP16_TAPS.pop(k, None)), weight._version, w9)
         _FP16_TAPS[key] = ent
     return ent[2]

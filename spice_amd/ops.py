@@ -691,6 +691,16 @@ def depthwise_conv(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, dilat
     return spice_ops().depthwise_conv(x, weight, int(stride), int(dilation), *_bn_parts(bn), int(act))
 
 
+def pooled_branch(x: torch.Tensor, weight2d: torch.Tensor, bn: "torch.nn.BatchNorm2d", act: int = 1,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The image-pooling branch of an ASPP in two launches: plane means of x [N,Cin,H,W] fp16 -> 1x1 convolution
+    with weight2d [Cout,Cin] fp16 -> bn (inference) -> activation (0 none, 1 ReLU, 2 SiLU) -> the value spread over
+    the plane, into `out` (a channel slice of a concatenation) when given.  What AdaptiveAvgPool2d(1), conv, bn, relu
+    and a bilinear up-sampling to x's size compute under fp16 autocast, to the order of the convolution's fp32 sum."""
+    return spice_ops().pooled_branch(x, weight2d, bn.running_mean, bn.running_var, bn.weight, bn.bias, float(bn.eps),
+                                     int(act), out)
+
+
 def squeeze_excite(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
     """x * sigmoid(conv1x1(silu(conv1x1(mean(x), w1, b1)), w2, b2)) for fp16 NCHW x and fp32 parameters (w1 [R,C,1,1] or
     [R,C], w2 [C,R,1,1] or [C,R]): the squeeze-and-excite of an EfficientNet block in four short launches, every

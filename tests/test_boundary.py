@@ -15,7 +15,7 @@ from spice_amd import ops
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 OPS = ["importance_run", "importance_cols_run", "gather_run", "confusion_update", "confusion_update_static",
-       "argmax_confusion_update", "kdlite_forward", "kdlite_label_pass", "gather_upload", "depthwise_conv", "squeeze_excite", "scale_inplace", "upsample_bilinear", "bn_act", "bn_act_dual",
+       "argmax_confusion_update", "kdlite_forward", "kdlite_label_pass", "gather_upload", "depthwise_conv", "squeeze_excite", "pooled_branch", "scale_inplace", "upsample_bilinear", "bn_act", "bn_act_dual",
        "bn_act_maxpool", "depthwise_conv3x3", "conv1x1_f16", "conv1x1_bn_act", "conv3x3_bn_act", "conv7x7_s2"]
 
 

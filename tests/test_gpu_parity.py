@@ -1075,3 +1075,41 @@ def test_head_3x3_convolution_with_bias_in_one_launch(dev, cin, cout, h, w):
     assert float((got.float() - there.float()).abs().max()) <= step
     with torch.autocast("cuda", dtype=torch.float16):
         assert conv(x).requires_grad
+
+
+@pytest.mark.parametrize("n,cin,h,w,cout", [(8, 2048, 32, 32, 256), (2, 205, 8, 24, 37), (1, 64, 5, 7, 3), (3, 320, 64, 64, 256)])
+def test_aspp_pooling_branch_in_two_launches(dev, n, cin, h, w, cout):
+    """ops.pooled_branch (plane means -> 1x1 convolution -> batch-norm -> ReLU -> spread over the plane) against the
+    module sequence it replaces under fp16 autocast (decoders.ASPPPooling on torch's route): the means bit for bit,
+    the result within one fp16 step of the fp64 evaluation of the same rounded steps and of torch's modules (their
+    convolution sums in another order); into a channel slice of a larger tensor; and the module takes the op."""
+    from spice_amd.nets import decoders, layers
+    torch.manual_seed(n + cin + cout)
+    m = decoders.ASPPPooling(cin, cout).to(dev).eval()
+    m.bn.running_mean.normal_(0.0, 0.2); m.bn.running_var.uniform_(0.5, 1.5)
+    m.bn.weight.data.uniform_(0.5, 1.5); m.bn.bias.data.normal_(0.0, 0.2)
+    x = torch.randn(n, cin, h, w, device=dev).half()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        layers.set_library_forward(False)
+        try:
+            there = m(x)
+        finally:
+            layers.set_library_forward(True)
+        assert m.served_by_library(x)
+        got = m(x)
+        big = torch.full((n, cout + 5, h, w), 7.0, device=dev, dtype=torch.float16)
+        m(x, out=big[:, 2:2 + cout])
+    assert got.shape == there.shape == (n, cout, h, w) and got.dtype == torch.float16
+    assert torch.equal(big[:, 2:2 + cout], got) and bool((big[:, :2] == 7).all()) and bool((big[:, 2 + cout:] == 7).all())
+    # every pixel of a plane holds the same value
+    assert torch.equal(got, got[:, :, :1, :1].expand_as(got))
+    # the same rounded steps in fp64
+    mean16 = x.double().mean((2, 3)).half()
+    w16 = m.conv.weight.detach().reshape(cout, cin).half()
+    conv16 = (mean16.double() @ w16.double().t()).half()
+    bn = m.bn
+    y = ((conv16.double() - bn.running_mean.double()) / torch.sqrt(bn.running_var.double() + bn.eps)
+         * bn.weight.detach().double() + bn.bias.detach().double()).half().clamp_min(0)
+    step = 2.0 ** -10 * max(float(y.abs().max()), 1.0)
+    assert float((got[:, :, 0, 0].double() - y.double()).abs().max()) <= 2 * step
+    assert float((got.double() - there.double()).abs().max()) <= 3 * step

@@ -14,6 +14,23 @@ lab = torch.from_numpy(synth.label_map(1234, 8, 512, 512, 21, "blocky", ignore_s
 RATIOS = DEFAULT_RATIOS if ARCH == "DeepLabV3Plus" and ENC == "resnet50" else (0.25, 0.5, 0.75)
 idx = list(range(int(sys.argv[1]), int(sys.argv[2])))
 reuse = len(sys.argv) > 3 and sys.argv[3] == "reuse"
+HOLD = []
+if os.environ.get("HOLD_DST") == "1":   # the sliced tensors of every candidate stay allocated: no address comes back
+    from spice_amd.engine import pruner as _pr
+    _empty = torch.empty
+    class _T:
+        @staticmethod
+        def empty(*a, **k):
+            t = _empty(*a, **k); HOLD.append(t); return t
+        def __getattr__(self, n): return getattr(torch, n)
+    _orig_run = _pr.SliceJob.run
+    def _run(self, keep_undo=False):
+        r = _orig_run(self, keep_undo)
+        for o, a, _, _ in self.entries:
+            t = o._parameters.get(a, None)
+            HOLD.append(t if t is not None else o._buffers.get(a))
+        return r
+    _pr.SliceJob.run = _run
 def run(lanes):
     sweep = SensitivitySweep(model, 21, RATIOS, ignored_layers=ignored)
     sweep.prefix_reuse = reuse

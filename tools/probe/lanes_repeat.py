@@ -17,12 +17,6 @@ reuse = len(sys.argv) > 3 and sys.argv[3] == "reuse"
 HOLD = []
 if os.environ.get("HOLD_DST") == "1":   # the sliced tensors of every candidate stay allocated: no address comes back
     from spice_amd.engine import pruner as _pr
-    _empty = torch.empty
-    class _T:
-        @staticmethod
-        def empty(*a, **k):
-            t = _empty(*a, **k); HOLD.append(t); return t
-        def __getattr__(self, n): return getattr(torch, n)
     _orig_run = _pr.SliceJob.run
     def _run(self, keep_undo=False):
         r = _orig_run(self, keep_undo)

@@ -1,3 +1,7 @@
+"""Do two-lane sweeps repeat the one-lane tables?  Candidates a .. b-1 of a sweep at [8,3,512,512] evaluated with one
+lane (twice: the reference and its own repeat), then twelve times with two lanes; prints the candidates whose confusion
+matrices differ and how often.  Usage: python3 tools/probe/lanes_repeat.py a b [whole|reuse] [architecture encoder]
+(HOLD_DST=1: every candidate's sliced tensors stay allocated, so that no address is handed out twice)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

@@ -1,3 +1,7 @@
+"""The 1x1 convolution kernel's forms on the shapes of a DeepLabV3+-ResNet-50 sweep (pruned channel counts included),
+each launched behind a kernel that fills the LDS of every compute unit with a pattern (quiet NaNs, signalling NaNs,
+ones): a kernel that reads LDS it has not written gives another result then.  Build tools/probe/poison_lds.so first
+(tools/README.md)."""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

@@ -274,6 +274,27 @@ def _plain_inference_norm(bn: nn.BatchNorm2d) -> bool:
             and bn._parameters["weight"].dtype == torch.float32 and bn._buffers["running_mean"].dtype == torch.float32)
 
 
+# Where the unit that is running may put its result: set by a pass that stops in front of a captured launch graph
+# (nets/prefix.py) to that graph's input buffer for the unit, so that the unit's last launch writes there and no copy
+# into the buffer follows.  A unit that can do so takes it (once); every other unit leaves it, and the copy is made.
+_unit_destination: Optional[torch.Tensor] = None
+
+
+def set_unit_destination(t: Optional[torch.Tensor]) -> None:
+    global _unit_destination
+    _unit_destination = t
+
+
+def take_unit_destination(shape, device) -> Optional[torch.Tensor]:
+    """The pending destination if it is a contiguous fp16 tensor of that shape on that device (then it is used up)."""
+    global _unit_destination
+    t = _unit_destination
+    if t is None or t.dtype != torch.float16 or tuple(t.shape) != tuple(shape) or t.device != device or not t.is_contiguous():
+        return None
+    _unit_destination = None
+    return t
+
+
 def _hooked(m: nn.Module) -> bool:
     return bool(m._forward_hooks or m._forward_pre_hooks)
 

@@ -21,6 +21,12 @@ from __future__ import annotations
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 
+import os
+
+# SPICE_UNIT_DEST=0: units never write into a captured graph's input buffers themselves (A/B measurements)
+_DIRECT = os.environ.get("SPICE_UNIT_DEST", "1") != "0"
+
+
 class StopForward(Exception):
     """Raised by a pass at the unit it was told to stop in front of."""
 
@@ -120,7 +126,18 @@ class _Pass:
             return tape.acts[name]
         if self.stop is not None and k >= self.stop:
             raise StopForward(name)
-        out = fn(*args)
+        dest = None
+        if _DIRECT and self.graph is not None and self.keep is not None:
+            dest = self.graph.statics.get(name)
+        if dest is not None and not isinstance(dest, (tuple, list)):
+            from . import layers
+            layers.set_unit_destination(dest)   # the unit may write its result into the graph's input buffer
+            try:
+                out = fn(*args)
+            finally:
+                layers.set_unit_destination(None)
+        else:
+            out = fn(*args)
         if self.recording:
             tape._store(name, out)
         if self.keep is not None:

@@ -42,10 +42,14 @@ class Bottleneck(nn.Module):
         h1 = conv1x1_bn(m["conv1"], m["bn1"], x)
         out = conv3x3_bn(conv2, bn2, h1)   # one launch of the library's kernel at inference, else None
         if out is not None:
+            # (the block's result straight into a captured graph's input buffer where a pass has named one)
+            dest = None
+            if layers._unit_destination is not None:
+                dest = layers.take_unit_destination((out.shape[0], conv3.out_channels, out.shape[2], out.shape[3]), out.device)
             if downsample is None:
-                return conv1x1_bn(conv3, bn3, out, x)
+                return conv1x1_bn(conv3, bn3, out, x, out=dest)
             ds = downsample._modules
-            return conv1x1_bn(conv3, bn3, out, ds["0"](x), ds["1"])
+            return conv1x1_bn(conv3, bn3, out, ds["0"](x), ds["1"], out=dest)
         # the 3x3 convolution on torch's route: bn2 (+ ReLU) rides along with conv3 at inference, whose kernel applies it
         # to the convolution's raw result on the way in
         raw = self.conv2(h1)

@@ -858,7 +858,7 @@ class _SuffixGraph:
         if any(d is not None and (v is None or d.shape != v.shape) for d, v in pairs):
             return False
         for d, v in pairs:
-            if d is not None:
+            if d is not None and d is not v:   # (a unit that wrote into the buffer itself hands the buffer back)
                 d.copy_(v)
         return True
 

@@ -675,9 +675,17 @@ def test_sweep_suffix_graphs_give_the_tables_of_the_eager_forward(dev):
         sweep.teacher_forward(other)
         info = sweep.capture_suffix_graphs(other)
         assert info["graphs"] == 2 * (len(sweep._tape) - 1)
-        got = sweep.run(x, lab)          # its teacher forward writes x's activations where the other batch's were
+        # (a bottleneck in front of a graph writes its result into the graph's input buffer itself: counted here)
+        from spice_amd.nets import layers as net_layers
+        taken, take = [], net_layers.take_unit_destination
+        net_layers.take_unit_destination = lambda *a: (taken.append(1), take(*a))[1]
+        try:
+            got = sweep.run(x, lab)          # its teacher forward writes x's activations where the other batch's were
+        finally:
+            net_layers.take_unit_destination = take
         launches = sum(l.graph_launches for l in sweep._lanes)
         assert launches > 100, launches
+        assert len(taken) > 100, len(taken)
         # a weight changed in place: the graphs (which hold the address of its old fp16 copy) are not used any more
         with torch.no_grad():
             model.encoder.layer3[0].conv1.weight.mul_(1.0)

@@ -40,3 +40,20 @@ with torch.no_grad():
         same = [bool(torch.equal(outs[0], o)) for o in outs[1:]]
         nan = [int(torch.isnan(o).sum()) for o in outs]
         print(name, "equal to the unpoisoned result:", same, "NaNs:", nan)
+
+# the 3x3 modes (pruned, odd channel counts; stride 2; dilation 2)
+# cin, cout, side, stride, dilation
+for (cin, cout, side, stride, dil) in ((461, 512, 32, 1, 2), (512, 512, 32, 1, 2), (410, 512, 32, 1, 2), (205, 256, 32, 1, 1), (64, 64, 128, 1, 1),
+                                      (57, 64, 128, 1, 1), (128, 128, 128, 2, 1), (115, 128, 128, 2, 1), (256, 256, 32, 1, 1), (231, 256, 32, 1, 1),
+                                      (128, 128, 64, 1, 1), (256, 256, 64, 2, 1), (230, 256, 64, 2, 1)):
+    x = torch.randn(8, cin, side, side, device=dev).half()
+    w9 = (torch.randn(cout, 9 * cin, device=dev) / (9 * cin) ** 0.5).half()
+    b = bn(cout)
+    with torch.no_grad():
+        outs = []
+        for pattern in (None, 0x7fc07fc0, 0x7f800001, 0x3c003c00):
+            if pattern is not None:
+                poison(pattern)
+            outs.append(ops.conv3x3_bn_act(x, w9, b, True, stride, dil).clone())
+            torch.cuda.synchronize()
+    print((cin, cout, side, stride, dil), [bool(torch.equal(outs[0], o)) for o in outs[1:]], [int(torch.isnan(o).sum()) for o in outs])

@@ -781,7 +781,8 @@ def test_sweep_plans_made_between_the_launches(dev):
             assert sum(l.graph_launches for l in sweep._lanes) > 0
         tables.append(out)
     assert torch.equal(tables[0]["confusion"], tables[1]["confusion"])
-    assert torch.equal(tables[0]["kd"], tables[1]["kd"])
+    # (the loss kernel sums its workgroups' partial sums in the order they finish)
+    assert torch.allclose(tables[0]["kd"], tables[1]["kd"], rtol=1e-5, atol=1e-7)
     fp32 = SensitivitySweep(model, 21, ratios=(0.5,), ignored_layers=ignored, autocast_dtype=None)
     assert fp32.may_need_solver_lookups(x)                  # the fp32 forward runs on torch's convolutions
 

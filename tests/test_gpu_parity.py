@@ -1113,3 +1113,34 @@ def test_aspp_pooling_branch_in_two_launches(dev, n, cin, h, w, cout):
     step = 2.0 ** -10 * max(float(y.abs().max()), 1.0)
     assert float((got[:, :, 0, 0].double() - y.double()).abs().max()) <= 2 * step
     assert float((got.double() - there.double()).abs().max()) <= 3 * step
+
+
+@pytest.mark.parametrize("encoder", ["resnet50", "timm-efficientnet-b3"])
+def test_unet_decoder_copies_in_fp16_change_no_value(dev, encoder):
+    """The U-Net decoder's nearest up-sampling and concatenation written in fp16 straight into the concatenation
+    buffer against autocast's way (up-sampling and concatenation in fp32, cast back by the convolution): copies of
+    fp16 values either way, so the logits are the same bit for bit; odd-sized and skip-less blocks included."""
+    from spice_amd import nets
+    from spice_amd.nets import decoders
+    torch.manual_seed(4)
+    model = nets.create_model("Unet", encoder, 7).to(dev).eval()
+    x = torch.randn(2, 3, 96, 160, device=dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        fast = model(x)
+        keep = decoders._fp16_inference
+        decoders._fp16_inference = lambda t: False
+        try:
+            plain = model(x)
+        finally:
+            decoders._fp16_inference = keep
+    assert fast.dtype == plain.dtype and torch.equal(fast, plain)
+    blk = decoders.UnetDecoderBlock(16, 8, 8).to(dev).eval()
+    a, s = torch.randn(3, 16, 5, 7, device=dev).half(), torch.randn(3, 8, 10, 14, device=dev).half()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        got = blk(a, s)
+        decoders._fp16_inference = lambda t: False
+        try:
+            want = blk(a, s)
+        finally:
+            decoders._fp16_inference = keep
+    assert torch.equal(got, want)
